@@ -1,0 +1,184 @@
+/*
+ * trl_hip.h -- C ABI of libtrl_hip.so, the MI355X (gfx950) learner hot path behind
+ * the activatedgeek/torchrl Python surface.
+ *
+ * The reference has no FFI layer (it is pure Python on torch); every entry point
+ * below therefore cites the Python code whose arithmetic it replaces.  The Python
+ * classes in torchrl_amd/ keep the reference names and call these through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative TRL_E* code on failure;
+ *     trl_last_error() gives the thread's last message.
+ *   - all `*_d` / unqualified data pointers are DEVICE pointers owned by the caller
+ *     (torch tensors' data_ptr()); `*_h` pointers are HOST pointers.
+ *   - `stream` is a hipStream_t (void* here so the header needs no HIP include);
+ *     NULL is the legacy default stream.  Nothing here allocates, frees or
+ *     synchronises: work is enqueued on `stream` and the call returns.
+ *   - thread-compatible: no mutable global state except the thread-local error text.
+ */
+#ifndef TRL_HIP_H
+#define TRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRL_OK 0
+#define TRL_EINVAL (-1) /* bad argument (shape, alignment, null pointer, unsupported size) */
+#define TRL_EHIP (-2)   /* a HIP runtime call or kernel launch failed */
+
+#define TRL_MAX_COLS 8
+
+/* storage dtype of a replay column / output dtype of a gathered column */
+#define TRL_F32 0
+#define TRL_U8 1
+
+/* GAE modes */
+#define TRL_GAE_REFERENCE 0 /* done ignored inside the trajectory (reference behaviour) */
+#define TRL_GAE_MASKED 1    /* (1-done) masks bootstrap and carry at every step (extension) */
+
+/* output layout of the GAE kernel */
+#define TRL_LAYOUT_TN 0 /* [T, N] like the inputs */
+#define TRL_LAYOUT_NT 1 /* [N, T] env-major: the order examples/ppo.py:61-64 concatenates in */
+
+/* loss kinds for the TD kernel */
+#define TRL_LOSS_MSE 0   /* reference: dqn_controller.py:77-78, ddpg_controller.py:112 */
+#define TRL_LOSS_HUBER 1 /* north-star variant, no reference counterpart */
+
+int trl_version(void);
+const char *trl_last_error(void);
+
+/* ------------------------------------------------------------------ replay ring (a-1)
+ * The ring is ONE device byte buffer of `capacity` records, `stride` bytes each
+ * (stride % 4 == 0).  Column c of a record lives at byte offset col_off[c] and is
+ * col_bytes[c] bytes wide, stored as col_dtype[c] (TRL_F32 or TRL_U8).  Logical row i
+ * (0 = oldest, the order torchrl/utils/storage.py:7-16 keeps by cat + slice) is the
+ * physical record (head + i) % capacity.
+ */
+typedef struct {
+  int32_t ncols;
+  int32_t col_off[TRL_MAX_COLS];   /* byte offset inside a record, multiple of 4 */
+  int32_t col_bytes[TRL_MAX_COLS]; /* bytes of the column inside a record          */
+  int32_t col_dtype[TRL_MAX_COLS]; /* TRL_F32 / TRL_U8                              */
+} trl_ring_layout;
+
+/* Replaces TensorTupleDataset.extend -> truncated_cat (storage.py:7-16, 27-37): writes
+ * k new rows at physical records (tail + j) % capacity, j in [0, k), where
+ * tail = (head + count) % capacity.  src[c] is a dense device array [k, col_bytes[c]]
+ * of the column's storage dtype.  Requires 0 < k <= capacity (the caller drops the
+ * rows that would not survive, storage.py:12-14, and advances head/count itself). */
+int trl_ring_push(void *ring, int64_t capacity, int64_t stride, const trl_ring_layout *layout,
+                  int64_t tail, const void *const *src, int64_t k, void *stream);
+
+/* Replaces TensorTupleDataset.__getitem__ with a LongTensor (storage.py:44-45, called
+ * from examples/dqn.py:40-41, examples/ddpg.py:40-41): dst[c][b] = column c of logical
+ * row idx[b].  idx is a device int64 array [B]; negative values wrap once (idx + count)
+ * like torch indexing.  out_dtype[c] may be TRL_F32 for a TRL_U8 column (exact cast,
+ * what torch.Tensor(uint8 ndarray) gives at storage.py:65-67); otherwise it must equal
+ * the storage dtype.  dst[c] is dense [B, width]. */
+int trl_gather_rows(const void *ring, int64_t capacity, int64_t stride,
+                    const trl_ring_layout *layout, int64_t head, int64_t count,
+                    const int64_t *idx, int64_t B, void *const *dst, const int32_t *out_dtype,
+                    void *stream);
+
+/* Same as trl_gather_rows for the contiguous logical range [start, start+B) -- the
+ * `buffer[:]` form of examples/a2c.py:41 and examples/ppo.py:50 -- with no index array. */
+int trl_gather_range(const void *ring, int64_t capacity, int64_t stride,
+                     const trl_ring_layout *layout, int64_t head, int64_t count, int64_t start,
+                     int64_t B, void *const *dst, const int32_t *out_dtype, void *stream);
+
+/* ------------------------------------------------------------------ sampler (a-1, host)
+ * Replaces `torch.randperm(len(buffer))[:batch_size]` (examples/dqn.py:40,
+ * examples/ddpg.py:40) bit for bit: torch's CPU randperm is a forward Fisher-Yates over
+ * raw 32-bit MT19937 draws, z = draw % (n - i), swap(r[i], r[i + z]) for i in [0, n-1).
+ * `mt` is the 624-word MT19937 state, `*left`/`*next` torch's position counters (the
+ * fields of at::CPUGeneratorImpl's legacy state).  Writes the first B entries to out_h
+ * (host int64) and advances the state by exactly n-1 draws so that the stream stays in
+ * lock-step with a reference process that called torch.randperm(n).  O(n) time, O(B) memory. */
+int trl_mt19937_seed(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, uint64_t seed);
+int trl_randperm_prefix(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, int64_t n, int64_t B,
+                        int64_t *out_h);
+
+/* ------------------------------------------------------------------ returns / GAE (a-3)
+ * Replaces the Python reverse loop of A2CController.compute_return
+ * (a2c_controller.py:38-43) and PPOController.compute_return (ppo_controller.py:41-46)
+ * for N envs at once.  reward, value: [T, N] f32 (env index contiguous); bootstrap: [N]
+ * = V(next_obs[T-1]) or 0 where done[T-1] (a2c_controller.py:32-36); done: [T, N] f32,
+ * read only when mode == TRL_GAE_MASKED (may be NULL otherwise).
+ *   delta = (r[t] + gamma * v[t+1]) - v[t];  gae = delta + gamma_lambda * gae;
+ *   returns[t] = gae + v[t];  adv[t] = returns[t] - v[t]          (examples/ppo.py:54)
+ * with gamma -> (float)gamma and gamma_lambda -> (float)(gamma * lmbda) (the product is
+ * formed in double first, as Python does), every operation rounded to f32 separately (no
+ * FMA contraction), so the result is bit-identical to the reference loop.  adv may be NULL.
+ * Hyper-parameters are doubles throughout this header because the reference holds them
+ * as Python floats and torch narrows them to f32 at the point of use. */
+int trl_gae_reverse_scan(const float *reward, const float *value, const float *done,
+                         const float *bootstrap, int64_t T, int64_t N, double gamma,
+                         double lmbda, int32_t mode, int32_t out_layout, float *returns,
+                         float *adv, void *stream);
+
+/* ------------------------------------------------------------------ fused losses (a-4)
+ * Workspace: every loss kernel reduces over the batch in two fixed-order stages, so
+ * results are run-to-run reproducible.  `ws` is a caller-owned device scratch of at
+ * least trl_loss_workspace_bytes() bytes. */
+int64_t trl_loss_workspace_bytes(void);
+
+/* DQN / Double-DQN TD target + loss + dL/dQ (dqn_controller.py:64-78).
+ *   q [B, A] online Q(s, .); q_next_target [B, A]; q_next_online [B, A] or NULL
+ *   (non-NULL selects the Double-DQN argmax of dqn_controller.py:68-69);
+ *   action/reward/done [B] f32 (the reference stores them as f32, storage.py:65-67).
+ *   y = reward + gamma * nq * (1 - done); loss = mean(l(y - q[b, a_b]))
+ *   loss_out[0] = loss; dq [B, A] = dloss/dq (zeros off the taken action), may be NULL. */
+int trl_td_loss(const float *q, const float *q_next_target, const float *q_next_online,
+                const float *action, const float *reward, const float *done, int64_t B, int32_t A,
+                double gamma, int32_t kind, double huber_delta, float *loss_out, float *dq, void *ws,
+                void *stream);
+
+/* DDPG critic target + MSE + dL/dcurrent_q (ddpg_controller.py:107-112):
+ *   y = reward + (1 - done) * gamma * next_q;  loss = mean(l(cur_q - y)). */
+int trl_ddpg_critic_loss(const float *cur_q, const float *next_q, const float *reward,
+                         const float *done, int64_t B, double gamma, int32_t kind,
+                         double huber_delta, float *loss_out, float *dcur_q, void *ws, void *stream);
+
+/* PPO clipped surrogate + value MSE + Normal entropy (ppo_controller.py:55-68) and the
+ * backward seeds of  loss = actor + alpha * critic - beta * entropy.
+ *   mean [B, A], log_std [A], value [B], action [B, A], old_logp [B, A], adv [B],
+ *   returns [B].  losses_out[0..2] = actor, critic, entropy; losses_out[3] = loss.
+ *   dmean [B, A], dvalue [B], dlog_std [A] (reduced over the batch); NULL skips all three. */
+int trl_ppo_loss(const float *mean, const float *log_std, const float *value, const float *action,
+                 const float *old_logp, const float *adv, const float *returns, int64_t B, int32_t A,
+                 double clip, double alpha, double beta, float *losses_out, float *dmean,
+                 float *dlog_std, float *dvalue, void *ws, void *stream);
+
+/* Normal log-prob per action dimension, the `dist.log_prob(action)` of
+ * ppo_controller.py:48 (shape [B, A], not summed). */
+int trl_normal_logp(const float *mean, const float *log_std, const float *action, int64_t B,
+                    int32_t A, float *logp, void *stream);
+
+/* A2C loss (a2c_controller.py:48-59): probs [B, A] is the actor's softmax output,
+ * value/action/returns [B].  losses_out as for PPO; dprobs [B, A], dvalue [B]. */
+int trl_a2c_loss(const float *probs, const float *value, const float *action, const float *returns,
+                 int64_t B, int32_t A, double alpha, double beta, float *losses_out, float *dprobs,
+                 float *dvalue, void *ws, void *stream);
+
+/* ------------------------------------------------------------------ update (a-4)
+ * One pass over a flat f32 parameter buffer: optional scale (1/world_size after the
+ * all-reduce), optional elementwise clamp (torch.nn.utils.clip_grad_value_,
+ * ppo_controller.py:72-73), then torch.optim.Adam's default update
+ * (dqn_controller.py:39, ppo_controller.py:15: betas (0.9, 0.999), eps 1e-8, no decay)
+ * in torch's single-tensor op order.  `step` is the 1-based step count.  The scaled /
+ * clamped gradient is written back to `grad` (clip_grad_value_ works in place). */
+int trl_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                  double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
+                  double clip_value /* <= 0: no clamp */, void *stream);
+
+/* target <- tau * source + (1 - tau) * target (ddpg_controller.py:42-57); tau == 1 is
+ * the hard sync of dqn_controller.py:85-86. */
+int trl_polyak(float *target, const float *source, int64_t n, double tau, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRL_HIP_H */

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+  config.addinivalue_line('markers', 'gpu: needs a HIP device (run on the MI355X box)')
+
+
+def pytest_collection_modifyitems(config, items):
+  import torch
+  if torch.cuda.is_available():
+    return
+  skip = pytest.mark.skip(reason='no HIP device')
+  for item in items:
+    if 'gpu' in item.keywords:
+      item.add_marker(skip)
+
+
+def load_golden(name):
+  return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope='session')
+def golden():
+  return load_golden

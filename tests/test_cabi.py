@@ -1,0 +1,90 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/trl_hip.h declares;
+host-only entry points (error text, argument validation, sampler) behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from torchrl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+  text = open(os.path.join(ROOT, 'include', 'trl_hip.h')).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(trl_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+  names = _declared()
+  assert len(names) >= 15
+  handle = C.CDLL(_lib.LIB_PATH)
+  for n in names:
+    assert hasattr(handle, n), 'libtrl_hip.so does not export %s' % n
+    assert n in _lib.PROTOTYPES, 'no ctypes prototype for %s' % n
+  assert sorted(_lib.PROTOTYPES) == names
+
+
+def test_version_and_error_text():
+  lib = _lib.lib()
+  assert lib.trl_version() >= 100
+  assert lib.trl_loss_workspace_bytes() > 0
+  # argument validation happens before any HIP call, so it is testable without a device
+  rc = lib.trl_gae_reverse_scan(None, None, None, None, 4, 4, 0.99, 0.95, 0, 0, None, None, None)
+  assert rc == -1 and b'null pointer' in lib.trl_last_error()
+  with pytest.raises(_lib.TrlError, match='null pointer'):
+    _lib.check(rc)
+  lay = _lib.RingLayout()
+  lay.ncols = 0
+  rc = lib.trl_gather_rows(None, 1, 4, C.byref(lay), 0, 1, None, 1, None, None, None)
+  assert rc == -1 and b'ncols' in lib.trl_last_error()
+
+
+def test_sampler_matches_golden(golden):
+  from torchrl_amd.utils.sampler import Mt19937Sampler, randperm_prefix
+  g = golden('sampler.npz')
+  for ci in range(int(g['n_cases'])):
+    seed = int(g['c%d_seed' % ci])
+    own = Mt19937Sampler(seed)
+    torch.manual_seed(seed)
+    for j, (n, b) in enumerate(g['c%d_calls' % ci]):
+      exp = g['c%d_out%d' % (ci, j)]
+      np.testing.assert_array_equal(own.randperm_prefix(int(n), int(b)).numpy(), exp)
+      np.testing.assert_array_equal(randperm_prefix(int(n), int(b)).numpy(), exp)
+    # torch's generator is where the reference's would be: the next draws agree
+    np.testing.assert_array_equal(torch.randint(0, 2 ** 31, (4,)).numpy(), g['c%d_next_u32' % ci])
+
+
+@pytest.mark.parametrize('n,b', [(1, 1), (2, 1), (2, 2), (7, 7), (624, 10), (625, 625), (1249, 3), (100003, 77)])
+def test_sampler_lockstep_with_torch(n, b):
+  from torchrl_amd.utils.sampler import randperm_prefix
+  torch.manual_seed(n * 1000 + b)
+  torch.rand(5)                                  # start mid-block
+  exp = [torch.randperm(n)[:b] for _ in range(3)]
+  tail = torch.randn(3)
+  torch.manual_seed(n * 1000 + b)
+  torch.rand(5)
+  got = [randperm_prefix(n, b) for _ in range(3)]
+  for a, e in zip(got, exp):
+    assert torch.equal(a, e)
+  assert torch.equal(torch.randn(3), tail)
+
+
+def test_sampler_rejects_bad_arguments():
+  from torchrl_amd.utils.sampler import randperm_prefix
+  with pytest.raises(_lib.TrlError):
+    randperm_prefix(5, 6)
+  with pytest.raises(_lib.TrlError):
+    randperm_prefix(2 ** 31, 4)
+
+
+def test_generator_argument():
+  from torchrl_amd.utils.sampler import randperm_prefix
+  g1 = torch.Generator().manual_seed(99)
+  g2 = torch.Generator().manual_seed(99)
+  assert torch.equal(randperm_prefix(1000, 50, generator=g1), torch.randperm(1000, generator=g2)[:50])
+  assert torch.equal(torch.rand(3, generator=g1), torch.rand(3, generator=g2))

@@ -1,0 +1,192 @@
+"""HIP replay ring vs the reference's FIFO semantics: golden fixtures, the numpy oracle, and
+size-independent properties at large sizes.  Bit-exact throughout (gathers move bytes)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import replay_oracle
+from torchrl_amd.utils.storage import TensorTupleDataset, TransitionTupleDataset, Transition
+from tests.helpers import FIELDS, transitions_from
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _cpu(cols):
+  return [c.cpu().numpy() for c in cols]
+
+
+def test_golden_scenarios(golden):
+  g = golden('storage.npz')
+  for si in range(int(g['n_scenarios'])):
+    p = 's%d_' % si
+    ds = TransitionTupleDataset(size=int(g[p + 'size']), device=DEV)
+    assert len(ds) == 0
+    for pi, _k in enumerate(g[p + 'pushes']):
+      ds.extend(transitions_from(g, '%spush%d_' % (p, pi)))
+      assert len(ds) == int(g[p + 'lens'][pi])
+      if (p + 'after%d_obs' % pi) in g.files:
+        got = _cpu(ds[:])
+        for fi, f in enumerate(FIELDS):
+          exp = g['%safter%d_%s' % (p, pi, f)]
+          assert got[fi].dtype == np.float32 and got[fi].shape == exp.shape, (si, pi, f)
+          np.testing.assert_array_equal(got[fi], exp)
+    idx = torch.from_numpy(np.array(g[p + 'idx']))
+    for index in (idx, idx.to(DEV)):
+      got = _cpu(ds[index])
+      for fi, f in enumerate(FIELDS):
+        np.testing.assert_array_equal(got[fi], g[p + 'gather_' + f])
+    got = _cpu(ds[0])
+    for fi, f in enumerate(FIELDS):
+      np.testing.assert_array_equal(got[fi], g[p + 'item0_' + f])
+    ds.truncate()
+    assert len(ds) == 0
+  ds = TransitionTupleDataset(size=3, device=DEV)
+  ds.extend([])
+  assert len(ds) == 0
+
+
+def test_uint8_storage_matches_float_reference(golden):
+  """Scenario 5 pushes uint8 frames; stored as uint8 here, gathered as float32 == reference."""
+  g = golden('storage.npz')
+  p = 's5_'
+  ds = TransitionTupleDataset(size=int(g[p + 'size']), device=DEV, obs_dtype=torch.uint8)
+  for pi, _k in enumerate(g[p + 'pushes']):
+    ds.extend(transitions_from(g, '%spush%d_' % (p, pi)))
+    got = _cpu(ds[:])
+    for fi, f in enumerate(FIELDS):
+      np.testing.assert_array_equal(got[fi], g['%safter%d_%s' % (p, pi, f)])
+  raw = TransitionTupleDataset(size=6, device=DEV, obs_dtype=torch.uint8, gather_obs_dtype=torch.uint8)
+  raw.extend(transitions_from(g, p + 'push0_'))
+  assert raw[:][0].dtype == torch.uint8
+  np.testing.assert_array_equal(raw[:][0].cpu().numpy(), g[p + 'push0_obs'])
+
+
+@pytest.mark.parametrize('n', [10, 20, 30, 40, 50])
+def test_unbounded_shapes(n):
+  """The reference's own test_storage.py::test_unbounded, on the device ring."""
+  ds = TensorTupleDataset(size=-1, device=DEV)
+  assert len(ds) == 0
+  x = [torch.randn(n, 2, 19), torch.randn(n, 4), torch.randn(n, 8), torch.randn(n, 16), torch.randn(n, 32)]
+  ds.extend(*x)
+  assert len(ds) == n
+  i = int(np.random.randint(0, n))
+  for v, ref in zip(ds[i], x):
+    assert v.dim() == len(ref.shape[1:]) and v.size(-1) == ref.size(-1)
+    assert torch.equal(v.cpu(), ref[i])
+  ds.truncate()
+  assert len(ds) == 0
+
+
+@pytest.mark.parametrize('n,size', [(10, 9), (20, 100), (30, 10), (40, 40), (50, 12)])
+def test_bounded_shapes(n, size):
+  """The reference's own test_storage.py::test_bounded, plus FIFO values."""
+  ds = TensorTupleDataset(size=size, device=DEV)
+  assert ds.size == size and len(ds) == 0
+  x = [torch.randn(n, 2), torch.randn(n, 4), torch.randn(n, 8, 12), torch.randn(n, 16), torch.randn(n, 32)]
+  ds.extend(*x)
+  assert len(ds) == min(n, size)
+  got = ds[:]
+  for v, ref in zip(got, x):
+    assert torch.equal(v.cpu(), ref[-size:] if n > size else ref)
+  ds.truncate()
+  assert len(ds) == 0
+
+
+def _random_transitions(rs, k, obs_shape, u8):
+  out = []
+  for _ in range(k):
+    if u8:
+      o, no = rs.randint(0, 256, obs_shape).astype(np.uint8), rs.randint(0, 256, obs_shape).astype(np.uint8)
+    else:
+      o, no = rs.randn(*obs_shape).astype(np.float32), rs.randn(*obs_shape).astype(np.float32)
+    out.append(Transition(o, np.int64(rs.randint(0, 6)), float(rs.randn()), no, bool(rs.rand() < 0.1)))
+  return out
+
+
+@pytest.mark.parametrize('obs_shape,u8,size', [((3,), False, 1000), ((4,), False, 257), ((84, 84, 4), True, 96),
+                                               ((5,), True, 50), ((300,), False, 64), ((7, 5), True, 33)])
+def test_random_pushes_vs_oracle(obs_shape, u8, size):
+  """Many wrapping pushes of varying k against the numpy FIFO, incl. Atari-shaped uint8
+  records (wide-column kernel) and ragged uint8 widths."""
+  rs = np.random.RandomState(hash((obs_shape, size)) & 0xffff)
+  ds = TransitionTupleDataset(size=size, device=DEV, obs_dtype=torch.uint8 if u8 else None)
+  ref = replay_oracle.FifoColumns(size=size)
+  for k in [1, 3, size // 2, size - 1, 2, size, 5, size + 7, 1]:
+    tl = _random_transitions(rs, max(k, 1), obs_shape, u8)
+    ds.extend(tl)
+    ref.extend_transitions(tl)
+    assert len(ds) == len(ref)
+    n = len(ref)
+    idx = rs.randint(-n, n, size=2 * n + 3).astype(np.int64)
+    for got, exp in zip(_cpu(ds[torch.from_numpy(idx)]), ref[idx]):
+      np.testing.assert_array_equal(got, exp)
+    for got, exp in zip(_cpu(ds[:]), ref[slice(None)]):
+      np.testing.assert_array_equal(got, exp)
+    for got, exp in zip(_cpu(ds[1:n:3]), ref[slice(1, n, 3)]):
+      np.testing.assert_array_equal(got, exp)
+
+
+def test_unbounded_growth_keeps_order():
+  ds = TensorTupleDataset(size=-1, device=DEV)
+  ref = replay_oracle.FifoColumns(size=-1)
+  rs = np.random.RandomState(3)
+  for k in [1, 1000, 30, 2000, 5000]:
+    a, b = rs.randn(k, 3).astype(np.float32), rs.randn(k, 1).astype(np.float32)
+    ds.extend(torch.from_numpy(a), torch.from_numpy(b))
+    ref.extend(a, b)
+  assert len(ds) == len(ref) == 8031
+  for got, exp in zip(_cpu(ds[:]), ref[slice(None)]):
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_sample_matches_reference_sampling_line():
+  """buffer.sample(B) == buffer[torch.randperm(len(buffer))[:B]] (examples/dqn.py:40-41),
+  same indices and same generator state afterwards."""
+  rs = np.random.RandomState(0)
+  ds = TransitionTupleDataset(size=5000, device=DEV)
+  ds.extend(_random_transitions(rs, 5000, (4,), False))
+  torch.manual_seed(123)
+  idx = torch.randperm(len(ds))[:256]
+  exp = _cpu(ds[idx])
+  after = torch.rand(2)
+  torch.manual_seed(123)
+  got = _cpu(ds.sample(256))
+  for a, b in zip(got, exp):
+    np.testing.assert_array_equal(a, b)
+  assert torch.equal(torch.rand(2), after)
+
+
+def test_errors_are_loud():
+  ds = TransitionTupleDataset(size=4, device=DEV)
+  ds.extend(_random_transitions(np.random.RandomState(1), 3, (2,), False))
+  with pytest.raises(IndexError):
+    ds[3]
+  with pytest.raises(IndexError):
+    ds[torch.tensor([0, 5])]
+  with pytest.raises(TypeError):
+    TensorTupleDataset(device=DEV).extend(torch.zeros(2, 2, dtype=torch.float64))
+  with pytest.raises(Exception):
+    TensorTupleDataset(device='cpu').extend(torch.zeros(2, 2))
+
+
+def test_large_ring_properties():
+  """1M-row Pendulum-shaped ring (BASELINE config 3): every gathered row must equal the row
+  that was pushed at that logical position, checked through a closed form of the content."""
+  N, B = 1_000_000, 65536
+  ds = TensorTupleDataset(size=N, device=DEV)
+  base = torch.arange(N + 1234, dtype=torch.float32, device=DEV)
+  def cols(lo, hi):
+    r = base[lo:hi]
+    return [torch.stack([r, r + 0.25, r + 0.5], 1), (r * 2).unsqueeze(1), (-r).unsqueeze(1),
+            torch.stack([r + 1, r + 1.25, r + 1.5], 1), (r % 2).unsqueeze(1)]
+  ds.extend(*cols(0, 600_000))
+  ds.extend(*cols(600_000, N + 1234))          # wraps: oldest surviving row is 1234
+  assert len(ds) == N
+  torch.manual_seed(5)
+  idx = torch.randint(0, N, (B,), device=DEV)
+  obs, act, rew, nobs, done = ds[idx]
+  r = (idx + 1234).float()
+  assert torch.equal(obs[:, 0], r) and torch.equal(obs[:, 2], r + 0.5)
+  assert torch.equal(act[:, 0], r * 2) and torch.equal(rew[:, 0], -r)
+  assert torch.equal(nobs[:, 1], r + 1.25) and torch.equal(done[:, 0], r % 2)

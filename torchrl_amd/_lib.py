@@ -1,0 +1,94 @@
+"""ctypes binding of libtrl_hip.so (declarations: include/trl_hip.h).
+
+There is no fallback: if the library is missing, or a kernel entry point is called
+without a HIP device, the call raises.  Build the library with
+`python -m torchrl_amd._build` (or `__graft_entry__.build()`).
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'lib', 'libtrl_hip.so')
+
+TRL_MAX_COLS = 8
+TRL_F32, TRL_U8 = 0, 1
+TRL_GAE_REFERENCE, TRL_GAE_MASKED = 0, 1
+TRL_LAYOUT_TN, TRL_LAYOUT_NT = 0, 1
+TRL_LOSS_MSE, TRL_LOSS_HUBER = 0, 1
+
+
+class RingLayout(C.Structure):
+  _fields_ = [('ncols', C.c_int32),
+              ('col_off', C.c_int32 * TRL_MAX_COLS),
+              ('col_bytes', C.c_int32 * TRL_MAX_COLS),
+              ('col_dtype', C.c_int32 * TRL_MAX_COLS)]
+
+
+class TrlError(RuntimeError):
+  pass
+
+
+_vp, _i64, _i32, _f64 = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+
+# name -> (restype, argtypes); every symbol declared in include/trl_hip.h
+PROTOTYPES = {
+    'trl_version': (C.c_int, []),
+    'trl_last_error': (C.c_char_p, []),
+    'trl_ring_push': (C.c_int, [_vp, _i64, _i64, C.POINTER(RingLayout), _i64, C.POINTER(_vp), _i64, _vp]),
+    'trl_gather_rows': (C.c_int, [_vp, _i64, _i64, C.POINTER(RingLayout), _i64, _i64, _vp, _i64,
+                                  C.POINTER(_vp), C.POINTER(_i32), _vp]),
+    'trl_gather_range': (C.c_int, [_vp, _i64, _i64, C.POINTER(RingLayout), _i64, _i64, _i64, _i64,
+                                   C.POINTER(_vp), C.POINTER(_i32), _vp]),
+    'trl_mt19937_seed': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.c_uint64]),
+    'trl_randperm_prefix': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp]),
+    'trl_gae_reverse_scan': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _i32, _i32, _vp, _vp, _vp]),
+    'trl_loss_workspace_bytes': (_i64, []),
+    'trl_td_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
+    'trl_ddpg_critic_loss': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
+    'trl_ppo_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64,
+                               _vp, _vp, _vp, _vp, _vp, _vp]),
+    'trl_normal_logp': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    'trl_a2c_loss': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp]),
+    'trl_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),
+    'trl_polyak': (C.c_int, [_vp, _vp, _i64, _f64, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+  """The loaded library; raises with a build hint if it is not there."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise TrlError('%s not found: build it with `python -m torchrl_amd._build` '
+                     '(there is no CPU fallback)' % LIB_PATH)
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+      fn = getattr(handle, name)   # AttributeError if the symbol is missing
+      fn.restype = res
+      fn.argtypes = args
+    _lib = handle
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    raise TrlError('libtrl_hip error %d: %s' % (rc, lib().trl_last_error().decode(errors='replace')))
+
+
+def stream_ptr(device=None):
+  """hipStream_t of torch's current stream on `device` as an integer."""
+  import torch
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(t, what):
+  """Kernel entry points take device memory only."""
+  if not t.is_cuda:
+    raise TrlError('%s must live on a HIP device (got %s); torchrl_amd has no CPU path' % (what, t.device))
+  return t
+
+
+def ptr(t):
+  return None if t is None else t.data_ptr()

@@ -1,0 +1,62 @@
+"""A2C controller on the GAE scan and fused loss kernels (reference: a2c_controller.py)."""
+import torch
+
+from ...controllers import Controller
+from ... import functional as F
+from ..models import A2CNet
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+
+
+class A2CController(Controller):
+  def __init__(self, obs_size, action_size,
+               gamma=0.99, lmbda=1.0, lr=1e-3,
+               alpha=0.5, beta=1.0, device=None,
+               hidden=256, process_group=None):
+    self.device = resolve_device(device)
+
+    self.ac_net = A2CNet(obs_size, action_size, hidden).to(self.device)
+    self._flat = FlatParams(self.ac_net)
+    self.ac_net_optim = FlatAdam(self._flat, lr=lr)
+    self._sync = GradSync(process_group)
+    self._sync.broadcast_params(self._flat)
+
+    self.gamma = gamma
+    self.lmbda = lmbda
+    self.alpha = alpha
+    self.beta = beta
+
+  def act(self, obs):
+    with torch.no_grad():
+      _, dist = self.ac_net(obs_to_tensor(obs, self.device))
+    return dist.sample().cpu().numpy()
+
+  def compute_return(self, obs, action, reward, next_obs, done):  # pylint: disable=unused-argument
+    """One env's rollout [T, .] -> returns [T, 1] (a2c_controller.py:29-45)."""
+    return self.compute_return_batched(obs.unsqueeze(1), reward.reshape(-1, 1),
+                                       next_obs[-1:], done.reshape(-1, 1)[-1])[0].reshape(-1, 1)
+
+  def compute_return_batched(self, obs, reward, last_next_obs, last_done, done=None, masked=False,
+                             env_major_out=False):
+    """N envs at once: obs [T, N, obs_size], reward [T, N], last_next_obs [N, obs_size],
+    last_done [N] -> (returns, advantages, values), each [T, N] ([N, T] with env_major_out
+    for the first two)."""
+    need_hip(self.device, 'A2CController.compute_return')
+    T, N = reward.shape
+    with torch.no_grad():
+      values = self.ac_net.critic(obs.reshape(T * N, -1)).view(T, N)
+      bootstrap = self.ac_net.critic(last_next_obs).view(N)
+      bootstrap = torch.where(last_done.reshape(N) != 0, torch.zeros_like(bootstrap), bootstrap)
+      returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
+                           env_major_out=env_major_out)
+    return returns, adv, values
+
+  def learn(self, obs, action, reward, next_obs, done, returns):  # pylint: disable=unused-argument
+    need_hip(self.device, 'A2CController.learn')
+    value, probs = self.ac_net.heads(obs)
+    loss, parts = F.a2c_loss(probs, value, action, returns, self.alpha, self.beta)
+
+    self.ac_net_optim.zero_grad()
+    loss.backward()
+    self.ac_net_optim.step(grad_scale=self._sync.all_reduce(self._flat))
+
+    return dict(actor_loss=parts[0], critic_loss=parts[1], entropy_loss=parts[2])

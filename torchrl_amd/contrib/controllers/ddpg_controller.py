@@ -1,0 +1,118 @@
+"""DDPG controller on the fused critic-target kernel (reference: ddpg_controller.py)."""
+import numpy as np
+import torch
+
+from ...controllers import Controller
+from ... import functional as F
+from ..models import DDPGActorNet, DDPGCriticNet
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+
+
+class OUNoise:
+  """Ornstein-Uhlenbeck exploration noise, one state of `action_dim` shared by all envs
+  (ddpg_controller.py:7-39): dx = theta * (mu - x) + sigma * N(0, 1), drawn from numpy's
+  global generator; sigma anneals max_sigma -> min_sigma over decay_period calls."""
+
+  def __init__(self, action_dim, mu=0.0, theta=0.15, max_sigma=0.3, min_sigma=0.3, decay_period=100000):
+    self.action_dim, self.mu, self.theta = action_dim, mu, theta
+    self.max_sigma, self.min_sigma, self.decay_period = max_sigma, min_sigma, decay_period
+    self.sigma = max_sigma
+    self.state, self.step = None, 0
+    self.reset()
+
+  def reset(self):
+    self.state = np.ones(self.action_dim) * self.mu
+    self.step = 0
+
+  def evolve_state(self):
+    drift = self.theta * (self.mu - self.state)
+    self.state = self.state + (drift + self.sigma * np.random.randn(self.action_dim))
+    return self.state
+
+  def get_action(self, action):
+    noisy = action + self.evolve_state()
+    frac = min(1.0, self.step / self.decay_period)
+    self.sigma = self.max_sigma - (self.max_sigma - self.min_sigma) * frac
+    self.step += 1
+    return noisy
+
+
+def polyak_average_(source, target, tau=1e-3):
+  """In-place target <- tau * source + (1 - tau) * target over two modules' parameters
+  (ddpg_controller.py:42-57), for callers that hold plain modules.  The controller itself
+  averages its flat buffers with one HIP launch (FlatParams.polyak_from)."""
+  if not isinstance(source, torch.nn.Module) or not isinstance(target, torch.nn.Module):
+    raise AssertionError('polyak_average_ takes two nn.Modules, got %s and %s' % (type(source), type(target)))
+  with torch.no_grad():
+    for s, t in zip(source.parameters(), target.parameters()):
+      t.copy_(tau * s + (1.0 - tau) * t)
+
+
+class DDPGController(Controller):
+  def __init__(self, obs_size, action_size,
+               action_low, action_high,
+               actor_lr=1e-4, critic_lr=1e-3, gamma=0.99,
+               tau=1e-2, n_reset_interval=100, device=None,
+               hidden=256, huber_delta=None, process_group=None):
+    self.device = resolve_device(device)
+    self.action_low = action_low
+    self.action_high = action_high
+
+    # creation order = the reference's, so equal seeds give equal initial weights
+    self.actor = DDPGActorNet(obs_size, action_size, hidden).to(self.device)
+    self.target_actor = DDPGActorNet(obs_size, action_size, hidden).to(self.device)
+    self._actor, self._target_actor = FlatParams(self.actor), FlatParams(self.target_actor)
+    self._target_actor.copy_from(self._actor)
+    self.actor_optim = FlatAdam(self._actor, lr=actor_lr)
+
+    self.critic = DDPGCriticNet(obs_size, action_size, hidden).to(self.device)
+    self.target_critic = DDPGCriticNet(obs_size, action_size, hidden).to(self.device)
+    self._critic, self._target_critic = FlatParams(self.critic), FlatParams(self.target_critic)
+    self._target_critic.copy_from(self._critic)
+    self.critic_optim = FlatAdam(self._critic, lr=critic_lr)
+
+    self._sync = GradSync(process_group)
+    self._sync.broadcast_params(self._actor, self._target_actor, self._critic, self._target_critic)
+
+    self.gamma = gamma
+    self.tau = tau
+    self.n_reset_interval = n_reset_interval
+    self.huber_delta = huber_delta
+    self.noise = OUNoise(action_size)
+
+  def act(self, obs):
+    with torch.no_grad():
+      action = self.actor(obs_to_tensor(obs, self.device)).cpu().numpy()
+    action = np.clip(self.noise.get_action(action), self.action_low, self.action_high)
+    if self.noise.step % self.n_reset_interval == 0:
+      self.noise.reset()
+    return action
+
+  def learn(self, obs, action, reward, next_obs, done):
+    need_hip(self.device, 'DDPGController.learn')
+    self.actor.train()
+    self.critic.train()
+
+    actor_loss = -self.critic(obs, self.actor(obs)).mean()
+
+    current_q = self.critic(obs, action)
+    with torch.no_grad():
+      next_q = self.target_critic(next_obs, self.target_actor(next_obs))
+    critic_loss = F.ddpg_critic_loss(current_q, next_q, reward, done, self.gamma,
+                                     huber_delta=self.huber_delta)
+
+    # Actor step first.  The reference back-propagates actor_loss into the critic's .grad too
+    # and then throws that away with critic_optim.zero_grad(); restricting the backward to
+    # the actor's parameters yields the same actor gradient without the wasted matmuls.
+    self.actor_optim.zero_grad()
+    torch.autograd.backward(actor_loss, inputs=self._actor.params)
+    self.actor_optim.step(grad_scale=self._sync.all_reduce(self._actor))
+
+    self.critic_optim.zero_grad()
+    critic_loss.backward()
+    self.critic_optim.step(grad_scale=self._sync.all_reduce(self._critic))
+
+    self._target_actor.polyak_from(self._actor, self.tau)
+    self._target_critic.polyak_from(self._critic, self.tau)
+
+    return dict(actor_loss=actor_loss.detach(), critic_loss=critic_loss.detach())

@@ -1,0 +1,82 @@
+"""DQN / Double-DQN controller on the fused TD kernel (reference: dqn_controller.py).
+
+Same constructor, `act` and `learn` as the reference.  `learn` computes the three Q tables
+with torch matmuls and hands them to one HIP kernel that forms the (double) target, the loss
+and dL/dQ in a single pass (csrc/trl_loss.hip: k_td_loss); Adam and the hard target sync are
+one launch each over flat parameter buffers.
+"""
+import numpy as np
+import torch
+
+from ...controllers import Controller
+from ...utils.schedule import ExpDecaySchedule
+from ... import functional as F
+from ..models import QNet
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+
+
+def epsilon_greedy(action_size: int, choices: np.ndarray, eps: float = 0.1):
+  """Batched epsilon-greedy over greedy `choices` (dqn_controller.py:8-24).
+
+  Row i is drawn from the categorical eps/A + (1 - eps) * onehot(choices[i]) with one
+  `np.random.choice` call per row, so numpy's global stream is consumed exactly as in the
+  reference.  Returns [n, 1]."""
+  n = len(choices)
+  pmf = np.full((n, action_size), eps / action_size, dtype=np.float32)
+  pmf[np.arange(n), choices] += 1.0 - eps
+  support = np.arange(action_size)
+  picks = np.array([np.random.choice(support, p=row) for row in pmf])
+  return picks[:, None]
+
+
+class DQNController(Controller):
+  def __init__(self, obs_size, action_size,
+               double_dqn=False, gamma=.99, lr=1e-3,
+               eps_max=1.0, eps_min=1e-2, n_eps_anneal=1000,
+               n_update_interval=5, device=None,
+               huber_delta=None, hidden=128, process_group=None):
+    self.action_size = action_size
+    self.device = resolve_device(device)
+
+    self.q_net = QNet(obs_size, action_size, hidden).to(self.device)
+    self.target_q_net = QNet(obs_size, action_size, hidden).to(self.device)
+    self._q = FlatParams(self.q_net)
+    self._target = FlatParams(self.target_q_net)
+    self._target.copy_from(self._q)            # target_q_net.load_state_dict(q_net.state_dict())
+    self.q_net_optim = FlatAdam(self._q, lr=lr)
+    self._sync = GradSync(process_group)
+    self._sync.broadcast_params(self._q, self._target)
+
+    self.double_dqn = double_dqn
+    self.gamma = gamma
+    self.n_update_interval = n_update_interval
+    self.huber_delta = huber_delta             # None = the reference's MSE
+    self.eps = ExpDecaySchedule(start=eps_max, end=eps_min, num_steps=n_eps_anneal)
+    self._steps = 0
+
+  def act(self, obs):
+    with torch.no_grad():
+      greedy = self.q_net(obs_to_tensor(obs, self.device)).argmax(dim=-1).cpu().numpy()
+    actions = epsilon_greedy(self.action_size, greedy, self.eps.value)
+    return [a[0] for a in actions]
+
+  def learn(self, obs, action, reward, next_obs, done):
+    need_hip(self.device, 'DQNController.learn')
+    self.q_net.train()
+    q = self.q_net(obs)
+    with torch.no_grad():
+      q_next_target = self.target_q_net(next_obs)
+      q_next_online = self.q_net(next_obs) if self.double_dqn else None
+    loss = F.td_loss(q, q_next_target, action, reward, done, self.gamma,
+                     q_next_online=q_next_online, huber_delta=self.huber_delta)
+
+    self.q_net_optim.zero_grad()
+    loss.backward()
+    self.q_net_optim.step(grad_scale=self._sync.all_reduce(self._q))
+
+    self._steps += 1
+    if self._steps % self.n_update_interval == 0:
+      self._target.copy_from(self._q)
+
+    # 0-d tensor left on the device: the reference's `.cpu()` here is a host sync per step
+    return dict(td_loss=loss.detach())

@@ -1,0 +1,78 @@
+"""PPO controller on the GAE scan and the fused clipped-surrogate kernel
+(reference: ppo_controller.py)."""
+import torch
+
+from ...controllers import Controller
+from ... import functional as F
+from ..models import ActorCriticNet
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+
+
+class PPOController(Controller):
+  def __init__(self, obs_size, action_size,
+               gamma=0.99, lmbda=1.0, lr=1e-3,
+               alpha=0.5, beta=1.0, clip_ratio=0.2,
+               max_grad_norm=1.0, device=None,
+               hidden=256, process_group=None):
+    self.device = resolve_device(device)
+
+    self.ac_net = ActorCriticNet(obs_size, action_size, hidden).to(self.device)
+    self._flat = FlatParams(self.ac_net)
+    self.ac_net_optim = FlatAdam(self._flat, lr=lr)
+    self._sync = GradSync(process_group)
+    self._sync.broadcast_params(self._flat)
+
+    self.gamma = gamma
+    self.lmbda = lmbda
+    self.alpha = alpha
+    self.beta = beta
+    self.clip_ratio = clip_ratio
+    self.max_grad_norm = max_grad_norm
+
+  def act(self, obs):
+    with torch.no_grad():
+      _, dist = self.ac_net(obs_to_tensor(obs, self.device))
+    return dist.sample().cpu().numpy()
+
+  def compute_return(self, obs, action, reward, next_obs, done):
+    """One env's rollout [T, .] -> (returns [T, 1], log_probs [T, A], values [T, 1])
+    (ppo_controller.py:32-51)."""
+    T = reward.shape[0]
+    returns, _, log_probs, values = self.compute_return_batched(
+        obs.unsqueeze(1), action.reshape(T, 1, -1), reward.reshape(T, 1), next_obs[-1:],
+        done.reshape(T, 1)[-1])
+    return returns.reshape(T, 1), log_probs.reshape(T, -1), values.reshape(T, 1)
+
+  def compute_return_batched(self, obs, action, reward, last_next_obs, last_done, done=None,
+                             masked=False, env_major_out=False):
+    """N envs at once: obs [T, N, obs_size], action [T, N, A], reward [T, N], last_next_obs
+    [N, obs_size], last_done [N] -> (returns, advantages, log_probs [T, N, A], values [T, N]).
+    With env_major_out, returns/advantages come back [N, T], the minibatch order of
+    examples/ppo.py:61-68."""
+    need_hip(self.device, 'PPOController.compute_return')
+    T, N = reward.shape
+    with torch.no_grad():
+      flat_obs = obs.reshape(T * N, -1)
+      values, mean, log_std = self.ac_net.heads(flat_obs)
+      values = values.view(T, N)
+      bootstrap = self.ac_net.critic(last_next_obs).view(N)
+      bootstrap = torch.where(last_done.reshape(N) != 0, torch.zeros_like(bootstrap), bootstrap)
+      returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
+                           env_major_out=env_major_out)
+      log_probs = F.normal_log_prob(mean, log_std, action.reshape(T * N, -1)).view(T, N, -1)
+    return returns, adv, log_probs, values
+
+  def learn(self, obs, action, reward, next_obs, done,  # pylint: disable=unused-argument
+            returns, old_log_probs, advantages):
+    need_hip(self.device, 'PPOController.learn')
+    value, mean, log_std = self.ac_net.heads(obs)
+    loss, parts = F.ppo_loss(mean, log_std, value, action, old_log_probs, advantages, returns,
+                             self.clip_ratio, self.alpha, self.beta)
+
+    self.ac_net_optim.zero_grad()
+    loss.backward()
+    # clip_grad_value_ (an elementwise clamp, ppo_controller.py:72-73) is folded into the
+    # Adam launch and applied after the data-parallel reduction
+    self.ac_net_optim.step(grad_scale=self._sync.all_reduce(self._flat), clip_value=self.max_grad_norm)
+
+    return dict(actor_loss=parts[0], critic_loss=parts[1], entropy_loss=parts[2])

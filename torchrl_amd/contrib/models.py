@@ -1,0 +1,133 @@
+"""Policy / value networks of the four controllers (reference: torchrl/contrib/models.py).
+
+These stay plain torch.nn modules: their matmuls run on PyTorch-ROCm (hipBLASLt / MFMA),
+the one place of the learner where matrix cores are used.  What has to hold for drop-in
+parity is (1) the parameter names, so a reference state_dict loads, (2) the order in which
+parameters are created and re-initialised, so that under the same torch seed the weights
+are bit-identical to the reference's, and (3) the forward arithmetic.  Hidden sizes are
+arguments here (an int keeps the reference's depth, a tuple stacks more layers, e.g. the
+"MLP 64x64" of the PPO benchmark); the defaults are the reference shapes.
+"""
+import torch
+from torch import nn
+from torch.distributions import Normal, Categorical
+
+
+def _as_sizes(hidden, depth):
+  """int -> `depth` hidden layers of that width; tuple/list -> as given."""
+  if isinstance(hidden, (tuple, list)):
+    return [int(h) for h in hidden]
+  return [int(hidden)] * depth
+
+
+def _mlp(n_in, hidden_sizes, n_out, tail=None):
+  """Linear/ReLU stack whose Linear layers sit at even Sequential indices (0, 2, 4, ...)."""
+  layers, width = [], n_in
+  for h in hidden_sizes:
+    layers += [nn.Linear(width, h), nn.ReLU()]
+    width = h
+  layers.append(nn.Linear(width, n_out))
+  if tail is not None:
+    layers.append(tail)
+  return nn.Sequential(*layers)
+
+
+def _last_linear(seq):
+  return [m for m in seq if isinstance(m, nn.Linear)][-1]
+
+
+class QNet(nn.Module):
+  """obs -> Q(s, .): in -> 128 -> 128 -> out (models.py:6-24)."""
+
+  def __init__(self, input_size, output_size, hidden=128):
+    super().__init__()
+    self._input_size, self._output_size = input_size, output_size
+    self._hidden_sizes = _as_sizes(hidden, 2)
+    self._hidden_size = self._hidden_sizes[0]
+    self.net = _mlp(input_size, self._hidden_sizes, output_size)
+
+  def forward(self, obs):
+    return self.net(obs)
+
+
+class DDPGActorNet(nn.Module):
+  """obs -> tanh action; last layer U(-3e-3, 3e-3) (models.py:27-53)."""
+
+  def __init__(self, state_size, action_size, hidden_size):
+    super().__init__()
+    self.state_size, self.action_size, self.hidden_size = state_size, action_size, hidden_size
+    self._weight_init = 3e-3
+    self.net = _mlp(state_size, _as_sizes(hidden_size, 2), action_size, tail=nn.Tanh())
+    out = _last_linear(self.net)
+    nn.init.uniform_(out.weight, -self._weight_init, self._weight_init)
+    nn.init.uniform_(out.bias, -self._weight_init, self._weight_init)
+
+  def forward(self, obs):
+    return self.net(obs)
+
+
+class DDPGCriticNet(nn.Module):
+  """(obs, action) -> Q; last layer U(-3e-3, 3e-3) (models.py:56-81)."""
+
+  def __init__(self, state_size, action_size, hidden_size):
+    super().__init__()
+    self.state_size, self.action_size, self.hidden_size = state_size, action_size, hidden_size
+    self._weight_init = 3e-3
+    self.net = _mlp(state_size + action_size, _as_sizes(hidden_size, 2), 1)
+    out = _last_linear(self.net)
+    nn.init.uniform_(out.weight, -self._weight_init, self._weight_init)
+    nn.init.uniform_(out.bias, -self._weight_init, self._weight_init)
+
+  def forward(self, obs, action):
+    return self.net(torch.cat([obs, action], dim=1))
+
+
+class A2CNet(nn.Module):
+  """Separate critic and softmax actor, one hidden layer each (models.py:84-109).
+
+  `forward` returns (value, Categorical); `heads` returns the raw (value, probs) pair that
+  the fused A2C loss kernel consumes.
+  """
+
+  def __init__(self, input_size, output_size, hidden_size):
+    super().__init__()
+    self._input_size, self._output_size, self._hidden_size = input_size, output_size, hidden_size
+    sizes = _as_sizes(hidden_size, 1)
+    self.critic = _mlp(input_size, sizes, 1)                                   # created first
+    self.actor = _mlp(input_size, sizes, output_size, tail=nn.Softmax(dim=1))
+
+  def heads(self, obs):
+    return self.critic(obs), self.actor(obs)
+
+  def forward(self, obs):
+    value, probs = self.heads(obs)
+    return value, Categorical(probs)
+
+
+class ActorCriticNet(nn.Module):
+  """Gaussian policy + critic; every Linear W ~ N(0, 0.1), b = 0.1 (models.py:112-147).
+
+  `heads` returns (value, mean, log_std) for the fused PPO kernels.
+  """
+
+  def __init__(self, input_size, output_size, hidden_size, std=0.0):
+    super().__init__()
+    self._input_size, self._output_size, self._hidden_size = input_size, output_size, hidden_size
+    sizes = _as_sizes(hidden_size, 1)
+    self.critic = _mlp(input_size, sizes, 1)
+    self.actor = _mlp(input_size, sizes, output_size)
+    self.log_std = nn.Parameter(torch.ones(1, output_size) * std)
+    self.apply(self.init_weights)   # module order = creation order: critic.*, then actor.*
+
+  def heads(self, obs):
+    return self.critic(obs), self.actor(obs), self.log_std
+
+  def forward(self, obs):
+    value, mean, log_std = self.heads(obs)
+    return value, Normal(mean, log_std.exp().expand_as(mean))
+
+  @staticmethod
+  def init_weights(module):
+    if isinstance(module, nn.Linear):
+      nn.init.normal_(module.weight, mean=0., std=0.1)
+      nn.init.constant_(module.bias, 0.1)

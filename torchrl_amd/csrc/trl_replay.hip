@@ -1,0 +1,408 @@
+// Replay ring: push (scatter k rows into the ring) and gather (logical index -> dense
+// per-column batches).  Replaces the cat+slice FIFO and fancy-index gather of
+// torchrl/utils/storage.py:7-16, 27-37, 44-45 (callers: examples/dqn.py:27-28, 40-41;
+// examples/ddpg.py:25-26, 40-41).
+//
+// HBM layout: one byte buffer of `capacity` records, `stride` bytes each; the columns of
+// a transition sit side by side inside its record, so a narrow transition (36-44 B for
+// Pendulum / CartPole) is ONE contiguous read instead of five 4-16 B reads in five
+// arrays, and an Atari-shaped record (2 x 28,224 B frames + 12 B) is a 56 KB stream.
+// Two gather kernels:
+//   k_gather_narrow  one lane per dword of a record region; a block takes 64 rows and
+//                    loads their 64 indices with one coalesced wave-wide load.
+//   k_gather_wide    one block per (row, 8 KiB chunk of a wide column), 16 B per lane,
+//                    or 4 B -> float4 per lane when a u8 column is cast to f32.
+// Both are pure HBM/L2 byte movers: no LDS tiling is needed because nothing is reused.
+#include "trl_common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // types the nontemporal builtins take
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ColArgs {
+  int32_t ncols;
+  int32_t off_dw[TRL_MAX_COLS];   // first dword of the column inside a record
+  int32_t w_bytes[TRL_MAX_COLS];  // column width in bytes
+  int32_t sdt[TRL_MAX_COLS];      // storage dtype
+  int32_t odt[TRL_MAX_COLS];      // dtype on the dense side (gather output / push source)
+  void *ptr[TRL_MAX_COLS];        // dense per-column arrays
+};
+
+// which column holds dword d of a record (-1: padding)
+struct Hit {
+  int c;
+  int off_dw;
+  int w_bytes;
+  int sdt;
+  int odt;
+  char *ptr;
+};
+
+__device__ __forceinline__ Hit find_col(const ColArgs &a, int d) {
+  Hit h{-1, 0, 0, 0, 0, nullptr};
+#pragma unroll
+  for (int i = 0; i < TRL_MAX_COLS; ++i) {
+    const int w_dw = (a.w_bytes[i] + 3) >> 2;
+    if (i < a.ncols && d >= a.off_dw[i] && d < a.off_dw[i] + w_dw) {
+      h.c = i;
+      h.off_dw = a.off_dw[i];
+      h.w_bytes = a.w_bytes[i];
+      h.sdt = a.sdt[i];
+      h.odt = a.odt[i];
+      h.ptr = (char *)a.ptr[i];
+    }
+  }
+  return h;
+}
+
+__device__ __forceinline__ int64_t logical_to_record(int64_t i, int64_t head, int64_t count,
+                                                     int64_t capacity) {
+  if (i < 0) i += count;           // torch-style negative index
+  i = i < 0 ? 0 : (i >= count ? count - 1 : i);  // never fault on a bad index
+  int64_t p = head + i;
+  if (p >= capacity) p -= capacity;
+  return p;
+}
+
+constexpr int NARROW_ROWS = 64;  // rows per block = one wave-wide index load
+
+template <bool RANGE>
+__global__ __launch_bounds__(256) void k_gather_narrow(
+    const uint32_t *__restrict__ ring, int64_t capacity, int64_t stride_dw, int64_t head,
+    int64_t count, const int64_t *__restrict__ idx, int64_t start, int64_t B, ColArgs a,
+    int region_off_dw, int region_dw, uint32_t magic) {
+  __shared__ int64_t s_rec[NARROW_ROWS];
+  const int64_t row0 = (int64_t)blockIdx.x * NARROW_ROWS;
+  const int nrows = (int)((B - row0) < NARROW_ROWS ? (B - row0) : NARROW_ROWS);
+  if (threadIdx.x < NARROW_ROWS) {  // wave 0: one coalesced 64 x 8 B index load
+    int64_t p = 0;
+    if ((int)threadIdx.x < nrows) {
+      const int64_t i = RANGE ? start + row0 + threadIdx.x : idx[row0 + threadIdx.x];
+      p = logical_to_record(i, head, count, capacity);
+    }
+    s_rec[threadIdx.x] = p * stride_dw;
+  }
+  __syncthreads();
+  const int total = nrows * region_dw;
+#pragma unroll 2
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int r = (int)(((uint64_t)(uint32_t)e * magic) >> 32);  // e / region_dw
+    const int d = e - r * region_dw + region_off_dw;
+    const Hit h = find_col(a, d);
+    if (h.c < 0) continue;
+    const uint32_t v = ring[s_rec[r] + d];
+    const int j = d - h.off_dw;
+    const int64_t orow = row0 + r;
+    if (h.sdt == TRL_F32) {
+      ((uint32_t *)h.ptr)[orow * (h.w_bytes >> 2) + j] = v;
+    } else if (h.odt == TRL_F32) {  // u8 storage, f32 batch (exact)
+      float *o = (float *)h.ptr + orow * h.w_bytes + 4 * j;
+      const int nb = h.w_bytes - 4 * j;
+      if (nb >= 4 && (h.w_bytes & 3) == 0) {
+        *(float4 *)o = make_float4((float)(v & 255u), (float)((v >> 8) & 255u),
+                                   (float)((v >> 16) & 255u), (float)(v >> 24));
+      } else {
+        for (int b = 0; b < (nb < 4 ? nb : 4); ++b) o[b] = (float)((v >> (8 * b)) & 255u);
+      }
+    } else {  // u8 -> u8
+      uint8_t *o = (uint8_t *)h.ptr + orow * h.w_bytes + 4 * j;
+      const int nb = h.w_bytes - 4 * j;
+      if (nb >= 4 && (h.w_bytes & 3) == 0) {
+        *(uint32_t *)o = v;
+      } else {
+        for (int b = 0; b < (nb < 4 ? nb : 4); ++b) o[b] = (uint8_t)(v >> (8 * b));
+      }
+    }
+  }
+}
+
+// ---- wide columns -------------------------------------------------------------------
+constexpr int WIDE_COPY_CHUNK = 8192;  // bytes of a column one block copies (2 x 16 B per lane)
+constexpr int WIDE_CAST_CHUNK = 4096;  // source bytes one block casts (4 x 4 B per lane -> 4 x float4)
+
+struct WideArgs {
+  int32_t ncols;
+  int32_t off_b[TRL_MAX_COLS];        // byte offset in the record (multiple of 16)
+  int32_t w_bytes[TRL_MAX_COLS];      // multiple of 16
+  int32_t cast[TRL_MAX_COLS];         // 1: u8 -> f32
+  int32_t chunk_start[TRL_MAX_COLS + 1];  // prefix sum of chunks per column
+  void *ptr[TRL_MAX_COLS];
+};
+
+template <bool RANGE>
+__global__ __launch_bounds__(256) void k_gather_wide(
+    const char *__restrict__ ring, int64_t capacity, int64_t stride, int64_t head, int64_t count,
+    const int64_t *__restrict__ idx, int64_t start, int64_t B, WideArgs a) {
+  const uint32_t chunks = (uint32_t)a.chunk_start[a.ncols];
+  const uint32_t b = blockIdx.x / chunks;
+  const uint32_t ch = blockIdx.x - b * chunks;
+  int off_b = 0, w = 0, cast = 0, c0 = 0;
+  char *dst = nullptr;
+#pragma unroll
+  for (int i = 0; i < TRL_MAX_COLS; ++i) {
+    if (i < a.ncols && (int)ch >= a.chunk_start[i] && (int)ch < a.chunk_start[i + 1]) {
+      off_b = a.off_b[i];
+      w = a.w_bytes[i];
+      cast = a.cast[i];
+      c0 = a.chunk_start[i];
+      dst = (char *)a.ptr[i];
+    }
+  }
+  const int64_t li = RANGE ? start + (int64_t)b : idx[b];  // block-uniform: a scalar load
+  const int64_t rec = logical_to_record(li, head, count, capacity);
+  const char *src = ring + rec * stride + off_b;
+  const int lc = (int)ch - c0;
+  if (!cast) {
+    const int base = lc * WIDE_COPY_CHUNK;
+    char *o = dst + (int64_t)b * w;
+    u32x4 v[2];
+    int pos[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pos[u] = base + (u * 256 + (int)threadIdx.x) * 16;
+      if (pos[u] < w) v[u] = __builtin_nontemporal_load((const u32x4 *)(src + pos[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (pos[u] < w) __builtin_nontemporal_store(v[u], (u32x4 *)(o + pos[u]));
+  } else {
+    const int base = lc * WIDE_CAST_CHUNK;
+    float *o = (float *)dst + (int64_t)b * w;
+    uint32_t v[4];
+    int pos[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      pos[u] = base + (u * 256 + (int)threadIdx.x) * 4;
+      if (pos[u] < w) v[u] = __builtin_nontemporal_load((const uint32_t *)(src + pos[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (pos[u] < w) {
+        const f32x4 f = {(float)(v[u] & 255u), (float)((v[u] >> 8) & 255u),
+                         (float)((v[u] >> 16) & 255u), (float)(v[u] >> 24)};
+        __builtin_nontemporal_store(f, (f32x4 *)(o + pos[u]));
+      }
+  }
+}
+
+// ---- push ---------------------------------------------------------------------------
+// src columns are dense [k, w_bytes].  Value of dword d of new row r (0 for padding).
+__device__ __forceinline__ uint32_t push_dword(const ColArgs &a, int64_t r, int d) {
+  const Hit h = find_col(a, d);
+  uint32_t v = 0;
+  if (h.c >= 0) {
+    const int j = d - h.off_dw;
+    if ((h.w_bytes & 3) == 0) {
+      v = ((const uint32_t *)h.ptr)[r * (h.w_bytes >> 2) + j];
+    } else {  // ragged u8 column: assemble the dword byte by byte
+      const uint8_t *s = (const uint8_t *)h.ptr + r * h.w_bytes + 4 * j;
+      const int nb = h.w_bytes - 4 * j;
+      for (int b = 0; b < (nb < 4 ? nb : 4); ++b) v |= (uint32_t)s[b] << (8 * b);
+    }
+  }
+  return v;
+}
+
+// One lane per dword of the k new records.
+__global__ __launch_bounds__(256) void k_ring_push(uint32_t *__restrict__ ring, int64_t capacity,
+                                                   int64_t stride_dw, int64_t tail, int64_t k,
+                                                   ColArgs a) {
+  const int64_t total = k * stride_dw;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / stride_dw;
+    const int d = (int)(e - r * stride_dw);
+    int64_t p = tail + r;
+    if (p >= capacity) p -= capacity;
+    ring[p * stride_dw + d] = push_dword(a, r, d);
+  }
+}
+
+// One lane per 16 B of the k new records (stride % 16 == 0): a quad that lies inside a
+// 16 B-shaped column is one uint4 copy, any other quad is assembled dword by dword.
+__global__ __launch_bounds__(256) void k_ring_push16(uint4 *__restrict__ ring, int64_t capacity,
+                                                     int64_t stride_q, int64_t tail, int64_t k,
+                                                     ColArgs a) {
+  const int64_t total = k * stride_q;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / stride_q;
+    const int q = (int)(e - r * stride_q);
+    int64_t p = tail + r;
+    if (p >= capacity) p -= capacity;
+    const Hit h = find_col(a, q * 4);
+    uint4 v;
+    if (h.c >= 0 && (h.off_dw & 3) == 0 && (h.w_bytes & 15) == 0 && ((uintptr_t)h.ptr & 15) == 0) {
+      v = ((const uint4 *)h.ptr)[r * (h.w_bytes >> 4) + (q - (h.off_dw >> 2))];
+    } else {
+      v.x = push_dword(a, r, q * 4 + 0);
+      v.y = push_dword(a, r, q * 4 + 1);
+      v.z = push_dword(a, r, q * 4 + 2);
+      v.w = push_dword(a, r, q * 4 + 3);
+    }
+    ring[p * stride_q + q] = v;
+  }
+}
+
+int check_layout(const char *fn, const trl_ring_layout *l, int64_t stride) {
+  TRL_REQUIRE(l != nullptr, "%s: null layout", fn);
+  TRL_REQUIRE(l->ncols >= 1 && l->ncols <= TRL_MAX_COLS, "%s: ncols=%d out of [1,%d]", fn, l->ncols,
+              TRL_MAX_COLS);
+  TRL_REQUIRE(stride > 0 && stride % 4 == 0, "%s: stride=%lld must be a positive multiple of 4", fn,
+              (long long)stride);
+  int64_t prev_end = 0;
+  for (int c = 0; c < l->ncols; ++c) {
+    TRL_REQUIRE(l->col_dtype[c] == TRL_F32 || l->col_dtype[c] == TRL_U8, "%s: column %d: bad dtype %d",
+                fn, c, l->col_dtype[c]);
+    TRL_REQUIRE(l->col_bytes[c] > 0, "%s: column %d: empty", fn, c);
+    TRL_REQUIRE(l->col_dtype[c] != TRL_F32 || l->col_bytes[c] % 4 == 0,
+                "%s: column %d: f32 column of %d bytes", fn, c, l->col_bytes[c]);
+    TRL_REQUIRE(l->col_off[c] % 4 == 0 && l->col_off[c] >= prev_end,
+                "%s: column %d: offset %d must be a multiple of 4 and columns must ascend without overlap",
+                fn, c, l->col_off[c]);
+    prev_end = (int64_t)l->col_off[c] + ((l->col_bytes[c] + 3) / 4) * 4;
+    TRL_REQUIRE(prev_end <= stride, "%s: column %d ends at %lld beyond stride %lld", fn, c,
+                (long long)prev_end, (long long)stride);
+  }
+  return TRL_OK;
+}
+
+constexpr int WIDE_MIN_BYTES = 1024;  // columns at least this wide (and 16 B-shaped) take the wide kernel
+
+bool is_wide(const trl_ring_layout *l, int c, int64_t stride) {
+  return l->col_bytes[c] >= WIDE_MIN_BYTES && l->col_bytes[c] % 16 == 0 && l->col_off[c] % 16 == 0 &&
+         stride % 16 == 0;
+}
+
+int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, int64_t stride,
+                const trl_ring_layout *layout, int64_t head, int64_t count, const int64_t *idx,
+                int64_t start, int64_t B, void *const *dst, const int32_t *out_dtype, void *stream) {
+  int rc = check_layout(fn, layout, stride);
+  if (rc) return rc;
+  TRL_REQUIRE(ring && dst && out_dtype, "%s: null pointer", fn);
+  TRL_REQUIRE(capacity > 0 && count > 0 && count <= capacity && head >= 0 && head < capacity,
+              "%s: need 0 < count <= capacity and 0 <= head < capacity (capacity=%lld head=%lld count=%lld)",
+              fn, (long long)capacity, (long long)head, (long long)count);
+  TRL_REQUIRE(B >= 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
+  if (range)
+    TRL_REQUIRE(start >= 0 && start + B <= count, "%s: range [%lld, %lld) outside [0, %lld)", fn,
+                (long long)start, (long long)(start + B), (long long)count);
+  else
+    TRL_REQUIRE(idx != nullptr || B == 0, "%s: null index array", fn);
+  if (B == 0) return TRL_OK;
+  hipStream_t st = (hipStream_t)stream;
+
+  ColArgs na{};
+  WideArgs wa{};
+  int region_lo = INT32_MAX, region_hi = 0;
+  for (int c = 0; c < layout->ncols; ++c) {
+    TRL_REQUIRE(dst[c] != nullptr, "%s: dst[%d] is null", fn, c);
+    const int od = out_dtype[c];
+    TRL_REQUIRE(od == layout->col_dtype[c] || (od == TRL_F32 && layout->col_dtype[c] == TRL_U8),
+                "%s: column %d: cannot gather dtype %d as %d", fn, c, layout->col_dtype[c], od);
+    const bool cast = od != layout->col_dtype[c];
+    if (is_wide(layout, c, stride) && ((uintptr_t)dst[c] % 16 == 0) && ((uintptr_t)ring % 16 == 0)) {
+      const int i = wa.ncols++;
+      wa.off_b[i] = layout->col_off[c];
+      wa.w_bytes[i] = layout->col_bytes[c];
+      wa.cast[i] = cast;
+      wa.ptr[i] = dst[c];
+      const int chunk = cast ? WIDE_CAST_CHUNK : WIDE_COPY_CHUNK;
+      wa.chunk_start[i + 1] = wa.chunk_start[i] + (int)trl_cdiv(layout->col_bytes[c], chunk);
+    } else {
+      TRL_REQUIRE((uintptr_t)dst[c] % 16 == 0, "%s: dst[%d] must be 16-byte aligned", fn, c);
+      const int i = na.ncols++;
+      na.off_dw[i] = layout->col_off[c] / 4;
+      na.w_bytes[i] = layout->col_bytes[c];
+      na.sdt[i] = layout->col_dtype[c];
+      na.odt[i] = od;
+      na.ptr[i] = dst[c];
+      const int lo = na.off_dw[i], hi = lo + (layout->col_bytes[c] + 3) / 4;
+      region_lo = lo < region_lo ? lo : region_lo;
+      region_hi = hi > region_hi ? hi : region_hi;
+    }
+  }
+  if (na.ncols > 0) {
+    const int region_dw = region_hi - region_lo;
+    TRL_REQUIRE((int64_t)region_dw * NARROW_ROWS < (1 << 22),
+                "%s: narrow region of %d dwords is too wide for the narrow kernel", fn, region_dw);
+    const uint32_t magic = (uint32_t)(((1ull << 32) + region_dw - 1) / region_dw);
+    const unsigned grid = (unsigned)trl_cdiv(B, NARROW_ROWS);
+    if (range)
+      hipLaunchKernelGGL(k_gather_narrow<true>, dim3(grid), dim3(256), 0, st, (const uint32_t *)ring,
+                         capacity, stride / 4, head, count, idx, start, B, na, region_lo, region_dw, magic);
+    else
+      hipLaunchKernelGGL(k_gather_narrow<false>, dim3(grid), dim3(256), 0, st, (const uint32_t *)ring,
+                         capacity, stride / 4, head, count, idx, start, B, na, region_lo, region_dw, magic);
+    TRL_CHECK_LAUNCH(fn);
+  }
+  if (wa.ncols > 0) {
+    const int64_t blocks = B * wa.chunk_start[wa.ncols];
+    TRL_REQUIRE(blocks < (1ll << 31), "%s: %lld blocks exceed the grid limit; split the batch", fn,
+                (long long)blocks);
+    if (range)
+      hipLaunchKernelGGL(k_gather_wide<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const char *)ring,
+                         capacity, stride, head, count, idx, start, B, wa);
+    else
+      hipLaunchKernelGGL(k_gather_wide<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const char *)ring,
+                         capacity, stride, head, count, idx, start, B, wa);
+    TRL_CHECK_LAUNCH(fn);
+  }
+  return TRL_OK;
+}
+
+}  // namespace
+
+extern "C" int trl_gather_rows(const void *ring, int64_t capacity, int64_t stride,
+                               const trl_ring_layout *layout, int64_t head, int64_t count,
+                               const int64_t *idx, int64_t B, void *const *dst,
+                               const int32_t *out_dtype, void *stream) {
+  return gather_impl("trl_gather_rows", false, ring, capacity, stride, layout, head, count, idx, 0, B, dst,
+                     out_dtype, stream);
+}
+
+extern "C" int trl_gather_range(const void *ring, int64_t capacity, int64_t stride,
+                                const trl_ring_layout *layout, int64_t head, int64_t count,
+                                int64_t start, int64_t B, void *const *dst, const int32_t *out_dtype,
+                                void *stream) {
+  return gather_impl("trl_gather_range", true, ring, capacity, stride, layout, head, count, nullptr, start,
+                     B, dst, out_dtype, stream);
+}
+
+extern "C" int trl_ring_push(void *ring, int64_t capacity, int64_t stride, const trl_ring_layout *layout,
+                             int64_t tail, const void *const *src, int64_t k, void *stream) {
+  const char *fn = "trl_ring_push";
+  int rc = check_layout(fn, layout, stride);
+  if (rc) return rc;
+  TRL_REQUIRE(ring && src, "%s: null pointer", fn);
+  TRL_REQUIRE(capacity > 0 && tail >= 0 && tail < capacity, "%s: need 0 <= tail < capacity", fn);
+  TRL_REQUIRE(k >= 0 && k <= capacity, "%s: k=%lld must be in [0, capacity=%lld]", fn, (long long)k,
+              (long long)capacity);
+  if (k == 0) return TRL_OK;
+  ColArgs a{};
+  a.ncols = layout->ncols;
+  const bool all16 = stride % 16 == 0 && (uintptr_t)ring % 16 == 0 && stride >= 256;
+  for (int c = 0; c < layout->ncols; ++c) {
+    TRL_REQUIRE(src[c] != nullptr, "%s: src[%d] is null", fn, c);
+    TRL_REQUIRE((uintptr_t)src[c] % 4 == 0, "%s: src[%d] must be 4-byte aligned", fn, c);
+    a.off_dw[c] = layout->col_off[c] / 4;
+    a.w_bytes[c] = layout->col_bytes[c];
+    a.sdt[c] = a.odt[c] = layout->col_dtype[c];
+    a.ptr[c] = (void *)src[c];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (all16) {
+    const int64_t total = k * (stride / 16);
+    const unsigned grid = (unsigned)(trl_cdiv(total, 256) < 8192 ? trl_cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(k_ring_push16, dim3(grid), dim3(256), 0, st, (uint4 *)ring, capacity, stride / 16,
+                       tail, k, a);
+  } else {
+    const int64_t total = k * (stride / 4);
+    const unsigned grid = (unsigned)(trl_cdiv(total, 256) < 8192 ? trl_cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(k_ring_push, dim3(grid), dim3(256), 0, st, (uint32_t *)ring, capacity, stride / 4,
+                       tail, k, a);
+  }
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}

@@ -1,0 +1,270 @@
+"""Torch-facing wrappers of the HIP kernels (C ABI: include/trl_hip.h).
+
+Every function here takes device tensors and enqueues kernels on torch's current stream.
+There is no CPU implementation behind any of them: a CPU tensor raises TrlError.
+The loss functions are autograd Functions whose forward runs the fused kernel (loss AND
+its backward seeds in one pass) and whose backward only scales the saved seeds.
+"""
+import torch
+
+from . import _lib
+from ._lib import TRL_GAE_MASKED, TRL_GAE_REFERENCE, TRL_LAYOUT_NT, TRL_LAYOUT_TN, TRL_LOSS_HUBER, TRL_LOSS_MSE
+
+_workspaces = {}
+
+
+def _ws(device):
+  """Per-device reduction scratch of the loss kernels (allocated once)."""
+  key = (device.index if device.index is not None else torch.cuda.current_device())
+  ws = _workspaces.get(key)
+  if ws is None:
+    ws = torch.empty(_lib.lib().trl_loss_workspace_bytes(), dtype=torch.uint8, device=device)
+    _workspaces[key] = ws
+  return ws
+
+
+def _f32c(t, what):
+  _lib.require_device(t, what)
+  if t.dtype != torch.float32:
+    raise TypeError('%s must be float32, got %s' % (what, t.dtype))
+  return t.contiguous()
+
+
+# ------------------------------------------------------------------------------ GAE
+def gae(reward, value, bootstrap, gamma, lmbda, done=None, masked=False, env_major_out=False,
+        want_adv=True):
+  """Reverse-scan GAE over [T, N] (a2c_controller.py:38-43, ppo_controller.py:41-46).
+
+  reward, value: [T, N] float32 on the device; bootstrap: [N] = V(next_obs[T-1]) or 0 where
+  the last step was terminal.  Returns (returns, adv) shaped [T, N], or [N, T] with
+  env_major_out (the concatenation order of examples/ppo.py:61-64).  `masked=True` applies
+  (1 - done) at every step (extension; the reference ignores mid-trajectory dones).
+  """
+  reward = _f32c(reward, 'reward')
+  value = _f32c(value, 'value')
+  bootstrap = _f32c(bootstrap, 'bootstrap')
+  if reward.dim() != 2 or value.shape != reward.shape or bootstrap.numel() != reward.shape[1]:
+    raise ValueError('expected reward/value [T, N] and bootstrap [N], got %s %s %s' %
+                     (tuple(reward.shape), tuple(value.shape), tuple(bootstrap.shape)))
+  T, N = reward.shape
+  if masked:
+    if done is None:
+      raise ValueError('masked GAE needs done')
+    done = _f32c(done, 'done')
+    if done.shape != reward.shape:
+      raise ValueError('done must be [T, N]')
+  shape = (N, T) if env_major_out else (T, N)
+  returns = torch.empty(shape, dtype=torch.float32, device=reward.device)
+  adv = torch.empty(shape, dtype=torch.float32, device=reward.device) if want_adv else None
+  with torch.cuda.device(reward.device):
+    _lib.check(_lib.lib().trl_gae_reverse_scan(
+        reward.data_ptr(), value.data_ptr(), _lib.ptr(done) if masked else None, bootstrap.data_ptr(),
+        T, N, float(gamma), float(lmbda), TRL_GAE_MASKED if masked else TRL_GAE_REFERENCE,
+        TRL_LAYOUT_NT if env_major_out else TRL_LAYOUT_TN, returns.data_ptr(), _lib.ptr(adv),
+        _lib.stream_ptr(reward.device)))
+  return returns, adv
+
+
+# ------------------------------------------------------------------------------ TD losses
+class _TdLoss(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, q, q_next_target, q_next_online, action, reward, done, gamma, kind, delta):
+    q = _f32c(q, 'q')
+    B, A = q.shape
+    qnt = _f32c(q_next_target, 'q_next_target')
+    qno = _f32c(q_next_online, 'q_next_online') if q_next_online is not None else None
+    action, reward, done = (_f32c(t, n).view(-1) for t, n in
+                            ((action, 'action'), (reward, 'reward'), (done, 'done')))
+    if qnt.shape != q.shape or (qno is not None and qno.shape != q.shape) or \
+        action.numel() != B or reward.numel() != B or done.numel() != B:
+      raise ValueError('td_loss: inconsistent shapes')
+    loss = torch.empty((), dtype=torch.float32, device=q.device)
+    need = ctx.needs_input_grad[0]
+    dq = torch.empty_like(q) if need else None
+    with torch.cuda.device(q.device):
+      _lib.check(_lib.lib().trl_td_loss(q.data_ptr(), qnt.data_ptr(), _lib.ptr(qno), action.data_ptr(),
+                                        reward.data_ptr(), done.data_ptr(), B, A, float(gamma), kind,
+                                        float(delta), loss.data_ptr(), _lib.ptr(dq), _ws(q.device).data_ptr(),
+                                        _lib.stream_ptr(q.device)))
+    if need:
+      ctx.save_for_backward(dq)
+    return loss
+
+  @staticmethod
+  def backward(ctx, g):
+    (dq,) = ctx.saved_tensors
+    return (dq * g,) + (None,) * 8
+
+
+def td_loss(q, q_next_target, action, reward, done, gamma, q_next_online=None, huber_delta=None):
+  """DQN / Double-DQN loss (dqn_controller.py:64-78) from the three Q tables.
+
+  q: Q_online(obs) [B, A] (differentiable); q_next_target: Q_target(next_obs);
+  q_next_online: Q_online(next_obs) for Double-DQN, else None.  MSE like the reference unless
+  huber_delta is given."""
+  kind = TRL_LOSS_MSE if huber_delta is None else TRL_LOSS_HUBER
+  return _TdLoss.apply(q, q_next_target, q_next_online, action, reward, done, gamma, kind,
+                       0.0 if huber_delta is None else huber_delta)
+
+
+class _DdpgCriticLoss(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, cur_q, next_q, reward, done, gamma, kind, delta):
+    shape = cur_q.shape
+    cur = _f32c(cur_q, 'current_q').view(-1)
+    B = cur.numel()
+    nxt, reward, done = (_f32c(t, n).view(-1) for t, n in
+                         ((next_q, 'next_q'), (reward, 'reward'), (done, 'done')))
+    if nxt.numel() != B or reward.numel() != B or done.numel() != B:
+      raise ValueError('ddpg_critic_loss: inconsistent shapes')
+    loss = torch.empty((), dtype=torch.float32, device=cur.device)
+    need = ctx.needs_input_grad[0]
+    d = torch.empty_like(cur) if need else None
+    with torch.cuda.device(cur.device):
+      _lib.check(_lib.lib().trl_ddpg_critic_loss(cur.data_ptr(), nxt.data_ptr(), reward.data_ptr(),
+                                                 done.data_ptr(), B, float(gamma), kind, float(delta),
+                                                 loss.data_ptr(), _lib.ptr(d), _ws(cur.device).data_ptr(),
+                                                 _lib.stream_ptr(cur.device)))
+    if need:
+      ctx.save_for_backward(d.view(shape))
+    return loss
+
+  @staticmethod
+  def backward(ctx, g):
+    (d,) = ctx.saved_tensors
+    return (d * g,) + (None,) * 6
+
+
+def ddpg_critic_loss(current_q, next_q, reward, done, gamma, huber_delta=None):
+  """mse_loss(current_q, reward + (1 - done) * gamma * next_q) (ddpg_controller.py:107-112)."""
+  kind = TRL_LOSS_MSE if huber_delta is None else TRL_LOSS_HUBER
+  return _DdpgCriticLoss.apply(current_q, next_q, reward, done, gamma, kind,
+                               0.0 if huber_delta is None else huber_delta)
+
+
+# ------------------------------------------------------------------------------ PPO
+def normal_log_prob(mean, log_std, action):
+  """Normal(mean, exp(log_std)).log_prob(action), per action dimension (ppo_controller.py:48)."""
+  mean = _f32c(mean, 'mean')
+  B, A = mean.shape
+  log_std = _f32c(log_std, 'log_std').view(-1)
+  action = _f32c(action, 'action')
+  if log_std.numel() != A or action.shape != mean.shape:
+    raise ValueError('normal_log_prob: inconsistent shapes')
+  out = torch.empty_like(mean)
+  with torch.cuda.device(mean.device):
+    _lib.check(_lib.lib().trl_normal_logp(mean.data_ptr(), log_std.data_ptr(), action.data_ptr(), B, A,
+                                          out.data_ptr(), _lib.stream_ptr(mean.device)))
+  return out
+
+
+class _PpoLoss(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, mean, log_std, value, action, old_logp, adv, returns, clip, alpha, beta):
+    mean = _f32c(mean, 'mean')
+    B, A = mean.shape
+    ls_shape, v_shape = log_std.shape, value.shape
+    log_std = _f32c(log_std, 'log_std').view(-1)
+    value = _f32c(value, 'value').view(-1)
+    action = _f32c(action, 'action')
+    old_logp = _f32c(old_logp, 'old_log_probs')
+    adv = _f32c(adv, 'advantages').view(-1)
+    returns = _f32c(returns, 'returns').view(-1)
+    if (log_std.numel() != A or value.numel() != B or action.shape != mean.shape or
+        old_logp.shape != mean.shape or adv.numel() != B or returns.numel() != B):
+      raise ValueError('ppo_loss: inconsistent shapes')
+    losses = torch.empty(4, dtype=torch.float32, device=mean.device)
+    need = any(ctx.needs_input_grad[:3])
+    dmean = torch.empty_like(mean) if need else None
+    dls = torch.empty_like(log_std) if need else None
+    dv = torch.empty_like(value) if need else None
+    with torch.cuda.device(mean.device):
+      _lib.check(_lib.lib().trl_ppo_loss(mean.data_ptr(), log_std.data_ptr(), value.data_ptr(),
+                                         action.data_ptr(), old_logp.data_ptr(), adv.data_ptr(),
+                                         returns.data_ptr(), B, A, float(clip), float(alpha), float(beta),
+                                         losses.data_ptr(), _lib.ptr(dmean), _lib.ptr(dls), _lib.ptr(dv),
+                                         _ws(mean.device).data_ptr(), _lib.stream_ptr(mean.device)))
+    if need:
+      ctx.save_for_backward(dmean, dls.view(ls_shape), dv.view(v_shape))
+    total, parts = losses[3], losses[:3]
+    ctx.mark_non_differentiable(parts)
+    return total, parts
+
+  @staticmethod
+  def backward(ctx, g, _gparts):
+    dmean, dls, dv = ctx.saved_tensors
+    return (dmean * g, dls * g, dv * g) + (None,) * 7
+
+
+def ppo_loss(mean, log_std, value, action, old_log_probs, advantages, returns, clip_ratio, alpha, beta):
+  """PPO clipped-surrogate loss (ppo_controller.py:55-68).
+
+  Returns (loss, parts): `loss = actor + alpha * critic - beta * entropy` is differentiable
+  w.r.t. mean, log_std and value; `parts` = [actor_loss, critic_loss, entropy_loss] detached."""
+  return _PpoLoss.apply(mean, log_std, value, action, old_log_probs, advantages, returns,
+                        clip_ratio, alpha, beta)
+
+
+# ------------------------------------------------------------------------------ A2C
+class _A2cLoss(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, probs, value, action, returns, alpha, beta):
+    probs = _f32c(probs, 'probs')
+    B, A = probs.shape
+    v_shape = value.shape
+    value = _f32c(value, 'value').view(-1)
+    action = _f32c(action, 'action').view(-1)
+    returns = _f32c(returns, 'returns').view(-1)
+    if value.numel() != B or action.numel() != B or returns.numel() != B:
+      raise ValueError('a2c_loss: inconsistent shapes')
+    losses = torch.empty(4, dtype=torch.float32, device=probs.device)
+    need = any(ctx.needs_input_grad[:2])
+    dp = torch.empty_like(probs) if need else None
+    dv = torch.empty_like(value) if need else None
+    with torch.cuda.device(probs.device):
+      _lib.check(_lib.lib().trl_a2c_loss(probs.data_ptr(), value.data_ptr(), action.data_ptr(),
+                                         returns.data_ptr(), B, A, float(alpha), float(beta),
+                                         losses.data_ptr(), _lib.ptr(dp), _lib.ptr(dv),
+                                         _ws(probs.device).data_ptr(), _lib.stream_ptr(probs.device)))
+    if need:
+      ctx.save_for_backward(dp, dv.view(v_shape))
+    total, parts = losses[3], losses[:3]
+    ctx.mark_non_differentiable(parts)
+    return total, parts
+
+  @staticmethod
+  def backward(ctx, g, _gparts):
+    dp, dv = ctx.saved_tensors
+    return (dp * g, dv * g) + (None,) * 4
+
+
+def a2c_loss(probs, value, action, returns, alpha, beta):
+  """A2C loss (a2c_controller.py:48-59) from the actor's softmax output and the critic's value."""
+  return _A2cLoss.apply(probs, value, action, returns, alpha, beta)
+
+
+# ------------------------------------------------------------------------------ update
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8,
+               grad_scale=1.0, clip_value=0.0):
+  """In-place torch.optim.Adam default update on flat float32 buffers (+ optional gradient
+  scale and elementwise clamp, torch.nn.utils.clip_grad_value_ at ppo_controller.py:72-73)."""
+  for t, n in ((param, 'param'), (grad, 'grad'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+    _lib.require_device(t, n)
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != param.numel():
+      raise ValueError('adam_step_: %s must be a contiguous float32 buffer of the parameter size' % n)
+  with torch.cuda.device(param.device):
+    _lib.check(_lib.lib().trl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
+                                        exp_avg_sq.data_ptr(), param.numel(), float(lr), float(betas[0]),
+                                        float(betas[1]), float(eps), int(step), float(grad_scale),
+                                        float(clip_value), _lib.stream_ptr(param.device)))
+
+
+def polyak_(target, source, tau):
+  """target <- tau * source + (1 - tau) * target on flat buffers (ddpg_controller.py:42-57)."""
+  for t, n in ((target, 'target'), (source, 'source')):
+    _lib.require_device(t, n)
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != target.numel():
+      raise ValueError('polyak_: %s must be a contiguous float32 buffer' % n)
+  with torch.cuda.device(target.device):
+    _lib.check(_lib.lib().trl_polyak(target.data_ptr(), source.data_ptr(), target.numel(), float(tau),
+                                     _lib.stream_ptr(target.device)))

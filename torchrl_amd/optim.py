@@ -1,0 +1,92 @@
+"""Flat parameter/gradient buffers and the one-launch Adam update.
+
+The reference calls `torch.optim.Adam(module.parameters(), lr=...)` with default betas/eps
+(dqn_controller.py:39, ddpg_controller.py:73,80, a2c_controller.py:14, ppo_controller.py:15).
+Here every parameter of a module is a view into ONE contiguous float32 buffer and every
+`.grad` a view into a second one, so that
+  * zero_grad is one memset,
+  * the data-parallel all-reduce is one collective on one buffer (parallel.py),
+  * clip_grad_value_ + Adam are one HIP kernel launch (csrc/trl_loss.hip: k_adam),
+  * hard target sync / Polyak averaging are one launch over the flat buffers.
+The module keeps working as an ordinary nn.Module (state_dict, load_state_dict, parameters).
+"""
+import torch
+
+from . import _lib
+from . import functional as F
+
+
+class FlatParams:
+  """Re-homes `module`'s parameters (in `parameters()` order) into flat buffers."""
+
+  def __init__(self, module):
+    self.module = module
+    self.params = [p for p in module.parameters()]
+    if not self.params:
+      raise ValueError('module has no parameters')
+    dev = self.params[0].device
+    for p in self.params:
+      if p.dtype != torch.float32 or p.device != dev:
+        raise TypeError('FlatParams needs float32 parameters on one device')
+    n = sum(p.numel() for p in self.params)
+    self.data = torch.empty(n, dtype=torch.float32, device=dev)
+    self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+    off = 0
+    with torch.no_grad():
+      for p in self.params:
+        k = p.numel()
+        self.data[off:off + k].copy_(p.data.reshape(-1))
+        p.data = self.data[off:off + k].view(p.shape)
+        p.grad = self.grad[off:off + k].view(p.shape)
+        off += k
+    self.numel = n
+    self.device = dev
+
+  def zero_grad(self):
+    """Zero in place: the .grad views must survive (autograd then accumulates into them)."""
+    self.grad.zero_()
+    off = 0
+    for p in self.params:        # re-attach a view a caller dropped (p.grad = None) or replaced
+      k = p.numel()
+      if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+        p.grad = self.grad[off:off + k].view(p.shape)
+      off += k
+
+  def copy_from(self, other):
+    """Hard sync: load_state_dict of an identically shaped module (dqn_controller.py:86)."""
+    self.data.copy_(other.data)
+
+  def polyak_from(self, source, tau):
+    F.polyak_(self.data, source.data, tau)
+
+
+class FlatAdam:
+  """torch.optim.Adam(lr=lr) semantics (betas (0.9, 0.999), eps 1e-8, no weight decay, no
+  amsgrad) over a FlatParams, as one kernel launch per step."""
+
+  def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    self.flat = flat
+    self.lr, self.betas, self.eps = lr, betas, eps
+    self.exp_avg = torch.zeros_like(flat.data)
+    self.exp_avg_sq = torch.zeros_like(flat.data)
+    self.step_count = 0
+
+  def zero_grad(self):
+    self.flat.zero_grad()
+
+  def step(self, grad_scale=1.0, clip_value=0.0):
+    if not self.flat.data.is_cuda:
+      raise _lib.TrlError('FlatAdam.step needs a HIP device (no CPU update path)')
+    self.step_count += 1
+    F.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
+                 self.lr, self.betas, self.eps, grad_scale, clip_value)
+
+  def state_dict(self):
+    return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                lr=self.lr, betas=self.betas, eps=self.eps)
+
+  def load_state_dict(self, sd):
+    self.step_count = int(sd['step'])
+    self.exp_avg.copy_(sd['exp_avg'])
+    self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+    self.lr, self.betas, self.eps = sd['lr'], tuple(sd['betas']), sd['eps']

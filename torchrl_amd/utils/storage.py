@@ -1,0 +1,360 @@
+"""Device-resident replay storage with the reference's surface.
+
+Drop-in for torchrl/utils/storage.py: `TensorTupleDataset(size, x).extend / len / [index] /
+truncate`, `Transition`, `TransitionTupleDataset.extend(list[Transition])`.  Behind it the
+reference's "cat the whole column and slice" FIFO (storage.py:7-16, O(capacity) per push)
+is a preallocated HBM ring of fixed-stride records (layout: csrc/trl_replay.hip), and
+`buf[LongTensor]` / `buf[:]` are HIP gather kernels that return dense per-column batches on
+the device.  Logical index 0 is always the oldest surviving row, as in the reference.
+
+Differences a caller can observe (all additive):
+  * rows live on a HIP device; results come back on that device (`.to(device)` in
+    examples/dqn.py:41 is then a no-op).  There is no CPU storage path.
+  * columns are stored as float32 (what `torch.Tensor(b)` yields at storage.py:65-67), or,
+    opt-in, as uint8 with an exact cast back to float32 at gather time.  A float64 column,
+    which the reference would keep as float64 through `torch.cat` promotion, is refused.
+  * `sample(batch_size)` = `self[torch.randperm(len(self))[:batch_size]]` with the same
+    indices and the same effect on torch's CPU generator, without the O(n) permutation.
+"""
+import ctypes as C
+from collections import namedtuple
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .. import _lib
+from .sampler import randperm_prefix
+
+Transition = namedtuple('Transition', ['obs', 'action', 'reward', 'next_obs', 'done'])
+
+_WIDE_BYTES = 1024        # must match WIDE_MIN_BYTES in csrc/trl_replay.hip
+_MIN_UNBOUNDED_ROWS = 1024
+_F32_PROMOTABLE = (torch.float32, torch.float16, torch.bfloat16, torch.uint8, torch.int8,
+                   torch.int16, torch.int32, torch.int64, torch.bool)
+
+
+def _default_device():
+  if not torch.cuda.is_available():
+    raise _lib.TrlError('torchrl_amd replay storage needs a HIP device; none is visible '
+                        '(there is no CPU fallback)')
+  return torch.device('cuda', torch.cuda.current_device())
+
+
+class _Layout:
+  """Record layout of one ring: offsets/widths per column + the ctypes mirror."""
+
+  def __init__(self, feat_shapes, storage_dtypes):
+    if len(feat_shapes) > _lib.TRL_MAX_COLS:
+      raise ValueError('at most %d columns per dataset, got %d' % (_lib.TRL_MAX_COLS, len(feat_shapes)))
+    self.feat_shapes = [tuple(s) for s in feat_shapes]
+    self.storage_dtypes = list(storage_dtypes)
+    self.widths = [int(np.prod(s, dtype=np.int64)) if len(s) else 1 for s in self.feat_shapes]
+    self.col_bytes = [w * (1 if d == torch.uint8 else 4) for w, d in zip(self.widths, self.storage_dtypes)]
+    off, offs, wide = 0, [], False
+    for nbytes in self.col_bytes:
+      is_wide = nbytes >= _WIDE_BYTES and nbytes % 16 == 0
+      wide = wide or is_wide
+      align = 16 if is_wide else 4
+      off = (off + align - 1) // align * align
+      offs.append(off)
+      off += (nbytes + 3) // 4 * 4
+    align = 16 if wide else 4
+    self.stride = (off + align - 1) // align * align
+    self.offsets = offs
+    self.c = _lib.RingLayout()
+    self.c.ncols = len(offs)
+    for i, (o, b, d) in enumerate(zip(offs, self.col_bytes, self.storage_dtypes)):
+      self.c.col_off[i] = o
+      self.c.col_bytes[i] = b
+      self.c.col_dtype[i] = _lib.TRL_U8 if d == torch.uint8 else _lib.TRL_F32
+
+  def same_as(self, other):
+    return (other is not None and self.feat_shapes == other.feat_shapes and
+            self.storage_dtypes == other.storage_dtypes)
+
+  @property
+  def ncols(self):
+    return len(self.offsets)
+
+
+class TensorTupleDataset(Dataset):
+  """Vectorized tuples of tensors in an HBM ring (reference: storage.py:19-48).
+
+  size:            maximum number of rows kept (FIFO); -1 = unbounded (the ring doubles).
+  x:               optional list of [n, ...] tensors to start from (examples/ppo.py:66).
+  device:          HIP device; default = device of the first tensors pushed if they are on
+                   one, else the current HIP device.  Bound lazily because the examples
+                   build the buffer before they know the device (examples/dqn.py:22-25).
+  storage_dtypes:  per-column torch.float32 (default) or torch.uint8.
+  gather_dtypes:   per-column dtype of gathered batches; default float32 for every column
+                   (the reference hands out float32), torch.uint8 allowed for uint8 columns.
+  """
+
+  def __init__(self, size: int = -1, x: Optional[List] = None, device=None,
+               storage_dtypes=None, gather_dtypes=None):
+    self.size = size
+    self._device = torch.device(device) if device is not None else None
+    self._storage_dtypes = storage_dtypes
+    self._gather_dtypes = gather_dtypes
+    self._layout = None
+    self._ring = None
+    self._capacity = 0
+    self._head = 0
+    self._count = 0
+    self._pin = None
+    if x is not None:
+      self.extend(*x)
+
+  # ------------------------------------------------------------------ introspection
+  @property
+  def device(self):
+    return self._device
+
+  @property
+  def capacity(self):
+    return self._capacity
+
+  @property
+  def row_bytes(self):
+    return 0 if self._layout is None else self._layout.stride
+
+  def __len__(self) -> int:
+    return self._count
+
+  # ------------------------------------------------------------------ push
+  def _bind(self, tensors):
+    if self._device is None:
+      on_dev = [t.device for t in tensors if t.is_cuda]
+      self._device = on_dev[0] if on_dev else _default_device()
+    if self._device.type != 'cuda':
+      raise _lib.TrlError('torchrl_amd replay storage lives on a HIP device, not %s' % self._device)
+
+  def _make_layout(self, tensors):
+    sd = self._storage_dtypes or [torch.float32] * len(tensors)
+    if len(sd) != len(tensors):
+      raise ValueError('storage_dtypes has %d entries for %d columns' % (len(sd), len(tensors)))
+    for d in sd:
+      if d not in (torch.float32, torch.uint8):
+        raise TypeError('columns are stored as float32 or uint8, not %s' % d)
+    return _Layout([t.shape[1:] for t in tensors], sd)
+
+  def _allocate(self, rows):
+    nbytes = rows * self._layout.stride
+    return torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+
+  def _grow(self, need):
+    """Unbounded mode: double the ring, oldest row moves to record 0."""
+    new_cap = max(_MIN_UNBOUNDED_ROWS, self._capacity)
+    while new_cap < need:
+      new_cap *= 2
+    new_ring = self._allocate(new_cap)
+    if self._count:
+      st = self._layout.stride
+      old = self._ring.view(self._capacity, st)
+      new = new_ring.view(new_cap, st)
+      first = min(self._count, self._capacity - self._head)
+      new[:first].copy_(old[self._head:self._head + first])
+      if first < self._count:
+        new[first:self._count].copy_(old[:self._count - first])
+    self._ring, self._capacity, self._head = new_ring, new_cap, 0
+
+  def extend(self, *tensor_list: List[torch.Tensor]):
+    """FIFO-append k rows per column; keeps the last `size` rows (storage.py:27-37)."""
+    tensors = [torch.as_tensor(t) for t in tensor_list]
+    if self._count > 0 and len(tensors) != self._layout.ncols:   # storage.py:31
+      raise AssertionError('expected %d columns, got %d' % (self._layout.ncols, len(tensors)))
+    if not tensors:
+      return
+    k = tensors[0].shape[0]
+    for t in tensors:
+      if t.dim() < 1 or t.shape[0] != k:
+        raise ValueError('every column must be [k, ...] with the same k')
+      if t.dtype not in _F32_PROMOTABLE:
+        raise TypeError('column dtype %s would not be float32 in the reference either; '
+                        'torchrl_amd stores float32/uint8 only' % t.dtype)
+    self._bind(tensors)
+    layout = self._make_layout(tensors)
+    if self._layout is None or self._count == 0:
+      if not layout.same_as(self._layout):     # first push, or new shapes after truncate()
+        if self._layout is None or layout.stride != self._layout.stride:
+          self._ring, self._capacity = None, 0
+        self._layout = layout
+      self._head = 0
+    elif not layout.same_as(self._layout):
+      raise ValueError('column shapes %s do not match the stored %s' %
+                       (layout.feat_shapes, self._layout.feat_shapes))
+    if k == 0:
+      return
+    if self.size > 0 and k > self.size:      # only the last `size` rows survive (storage.py:12-14)
+      tensors = [t[k - self.size:] for t in tensors]
+      k = self.size
+    if self._ring is None:
+      self._capacity = self.size if self.size > 0 else max(_MIN_UNBOUNDED_ROWS, k)
+      self._ring = self._allocate(self._capacity)
+    if self.size <= 0 and self._count + k > self._capacity:
+      self._grow(self._count + k)
+
+    src = []
+    for t, sdt in zip(tensors, self._layout.storage_dtypes):
+      t = t.reshape(k, -1)
+      if t.dtype != sdt:
+        t = t.to(sdt)
+      src.append(t.to(self._device, non_blocking=True).contiguous())
+    tail = (self._head + self._count) % self._capacity
+    srcp = (C.c_void_p * len(src))(*[s.data_ptr() for s in src])
+    with torch.cuda.device(self._device):
+      _lib.check(_lib.lib().trl_ring_push(self._ring.data_ptr(), self._capacity, self._layout.stride,
+                                          C.byref(self._layout.c), tail, srcp, k,
+                                          _lib.stream_ptr(self._device)))
+    for s in src:   # keep staging alive until the stream has consumed it
+      s.record_stream(torch.cuda.current_stream(self._device))
+    over = self._count + k - self._capacity
+    if over > 0:
+      self._head = (self._head + over) % self._capacity
+      self._count = self._capacity
+    else:
+      self._count += k
+
+  # ------------------------------------------------------------------ gather
+  def _out_dtypes(self):
+    gd = self._gather_dtypes or [torch.float32] * self._layout.ncols
+    for g, s in zip(gd, self._layout.storage_dtypes):
+      if g != torch.float32 and g != s:
+        raise TypeError('cannot gather a %s column as %s' % (s, g))
+    return gd
+
+  def _alloc_out(self, B):
+    gd = self._out_dtypes()
+    outs = [torch.empty((B,) + shp, dtype=g, device=self._device)
+            for shp, g in zip(self._layout.feat_shapes, gd)]
+    dstp = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    odt = (C.c_int32 * len(outs))(*[_lib.TRL_U8 if g == torch.uint8 else _lib.TRL_F32 for g in gd])
+    return outs, dstp, odt
+
+  def _gather_range(self, start, B):
+    outs, dstp, odt = self._alloc_out(B)
+    if B:
+      with torch.cuda.device(self._device):
+        _lib.check(_lib.lib().trl_gather_range(self._ring.data_ptr(), self._capacity, self._layout.stride,
+                                               C.byref(self._layout.c), self._head, self._count, start, B,
+                                               dstp, odt, _lib.stream_ptr(self._device)))
+    return outs
+
+  def _gather_index(self, idx):
+    """idx: int64 tensor [B] on the device."""
+    B = idx.numel()
+    outs, dstp, odt = self._alloc_out(B)
+    if B:
+      with torch.cuda.device(self._device):
+        _lib.check(_lib.lib().trl_gather_rows(self._ring.data_ptr(), self._capacity, self._layout.stride,
+                                              C.byref(self._layout.c), self._head, self._count,
+                                              idx.data_ptr(), B, dstp, odt, _lib.stream_ptr(self._device)))
+    return outs
+
+  def _index_to_device(self, index):
+    """Host int64 indices -> device, through a small pinned staging ring (no pageable copy)."""
+    n = index.numel()
+    if self._pin is None or self._pin[0][0].numel() < n:
+      cap = max(4096, 1 << (max(n, 1) - 1).bit_length())
+      self._pin = [(torch.empty(cap, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+      self._pin_next = 0
+      self._pin_used = [False] * 4
+    slot = self._pin_next
+    self._pin_next = (slot + 1) % len(self._pin)
+    buf, ev = self._pin[slot]
+    if self._pin_used[slot]:
+      ev.synchronize()            # the copy issued 4 gathers ago has long finished
+    buf[:n].copy_(index)
+    dev = buf[:n].to(self._device, non_blocking=True)
+    ev.record(torch.cuda.current_stream(self._device))
+    self._pin_used[slot] = True
+    return dev
+
+  def __getitem__(self, index) -> List[torch.Tensor]:
+    if self._layout is None or self._count == 0:
+      if isinstance(index, slice) and self._layout is not None:
+        return self._gather_range(0, 0)
+      raise TypeError("'NoneType' object is not iterable")   # what the reference raises when empty
+    n = self._count
+    if isinstance(index, slice):
+      start, stop, step = index.indices(n)
+      if step == 1:
+        return self._gather_range(start, max(0, stop - start))
+      index = torch.arange(start, stop, step, dtype=torch.int64)
+    if isinstance(index, (int, np.integer)):
+      i = int(index)
+      if i < -n or i >= n:
+        raise IndexError('index %d is out of bounds for dimension 0 with size %d' % (i, n))
+      return [o[0] for o in self._gather_range(i % n, 1)]
+    if isinstance(index, (list, tuple, np.ndarray)):
+      index = torch.as_tensor(np.asarray(index))
+    if not torch.is_tensor(index) or index.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8,
+                                                         torch.int8):
+      raise TypeError('index must be an int, a slice or an integer tensor, got %r' % (type(index),))
+    if index.dim() == 0:
+      return self.__getitem__(int(index))
+    if index.dim() != 1:
+      raise IndexError('only 1-D index tensors are supported')
+    if index.dtype != torch.int64:
+      index = index.to(torch.int64)
+    if index.is_cuda:
+      # device-resident indices are not validated (no host sync); out-of-range clamps
+      idx = index.to(self._device).contiguous()
+    else:
+      if index.numel() and (int(index.min()) < -n or int(index.max()) >= n):
+        raise IndexError('index out of range for %d rows' % n)
+      idx = self._index_to_device(index.contiguous())
+    return self._gather_index(idx)
+
+  def sample(self, batch_size, generator=None):
+    """`self[torch.randperm(len(self), generator=generator)[:batch_size]]` (examples/dqn.py:40-41):
+    identical indices, identical generator state afterwards."""
+    idx = randperm_prefix(self._count, batch_size, generator)
+    return self._gather_index(self._index_to_device(idx))
+
+  def iter_batches(self, batch_size):
+    """Sequential minibatches, last partial batch kept: the order of
+    `DataLoader(ds, batch_size=...)` at examples/ppo.py:68 without per-row collation."""
+    for start in range(0, self._count, batch_size):
+      yield self._gather_range(start, min(batch_size, self._count - start))
+
+  def truncate(self):
+    """Drop every row (storage.py:47-48); the allocation is kept for the next rollout."""
+    self._head = 0
+    self._count = 0
+
+
+class TransitionTupleDataset(TensorTupleDataset):
+  """Replay of `Transition`s (reference: storage.py:60-72).
+
+  obs_dtype=torch.uint8 stores obs/next_obs as uint8 (4x the capacity for Atari-shaped
+  frames); gathered batches are float32 either way, bit-identical to what the reference
+  returns for uint8 observations.
+  """
+
+  def __init__(self, size: int = -1, device=None, obs_dtype=None, gather_obs_dtype=None):
+    sd = gd = None
+    if obs_dtype is not None:
+      sd = [obs_dtype, torch.float32, torch.float32, obs_dtype, torch.float32]
+      g = gather_obs_dtype or torch.float32
+      gd = [g, torch.float32, torch.float32, g, torch.float32]
+    super().__init__(size=size, device=device, storage_dtypes=sd, gather_dtypes=gd)
+
+  def extend(self, transition_list: List[Transition]):  # pylint: disable=arguments-differ
+    if len(transition_list) == 0:
+      return
+    cols = []
+    for ci, field in enumerate(zip(*transition_list)):
+      if torch.is_tensor(field[0]):
+        b = torch.stack([f.detach() for f in field])
+      else:
+        b = torch.from_numpy(np.asarray(field))
+      want = self._storage_dtypes[ci] if self._storage_dtypes else torch.float32
+      if b.dtype != want:
+        b = b.to(want)       # torch.Tensor(b) -> float32 (storage.py:65-67)
+      if b.dim() == 1:
+        b = b.unsqueeze(-1)  # storage.py:68-71
+      cols.append(b)
+    super().extend(*cols)
