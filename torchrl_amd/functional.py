@@ -32,7 +32,7 @@ def _f32c(t, what):
 
 # ------------------------------------------------------------------------------ GAE
 def gae(reward, value, bootstrap, gamma, lmbda, done=None, masked=False, env_major_out=False,
-        want_adv=True):
+        want_adv=True, out=None):
   """Reverse-scan GAE over [T, N] (a2c_controller.py:38-43, ppo_controller.py:41-46).
 
   reward, value: [T, N] float32 on the device; bootstrap: [N] = V(next_obs[T-1]) or 0 where
@@ -54,8 +54,15 @@ def gae(reward, value, bootstrap, gamma, lmbda, done=None, masked=False, env_maj
     if done.shape != reward.shape:
       raise ValueError('done must be [T, N]')
   shape = (N, T) if env_major_out else (T, N)
-  returns = torch.empty(shape, dtype=torch.float32, device=reward.device)
-  adv = torch.empty(shape, dtype=torch.float32, device=reward.device) if want_adv else None
+  if out is not None:           # caller-owned outputs (no allocation on the hot path)
+    returns, adv = out
+    for o in (returns, adv):
+      if o is not None and (o.shape != shape or o.dtype != torch.float32 or not o.is_contiguous()
+                            or o.device != reward.device):
+        raise ValueError('gae: out tensors must be contiguous float32 %s on %s' % (shape, reward.device))
+  else:
+    returns = torch.empty(shape, dtype=torch.float32, device=reward.device)
+    adv = torch.empty(shape, dtype=torch.float32, device=reward.device) if want_adv else None
   with torch.cuda.device(reward.device):
     _lib.check(_lib.lib().trl_gae_reverse_scan(
         reward.data_ptr(), value.data_ptr(), _lib.ptr(done) if masked else None, bootstrap.data_ptr(),
