@@ -1,0 +1,383 @@
+#!/usr/bin/env python3
+"""Benchmark of the learner hot path (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ppo|ddpg|dqn_atari]
+
+Default workload = BASELINE.json configs[1]: PPO on a synthetic rollout T=2048, N_envs=4096
+per GPU, MLP 64x64.  One "step" is one full pass of the on-policy hot path over that rollout,
+inputs already resident in HBM: value/policy forward over the rollout, the GAE reverse scan,
+log-probs, then n_epochs x (T*N / minibatch) learn() calls (fused clipped-surrogate loss,
+backward, [all-reduce], fused clip+Adam).  value = learner transitions/s = transitions fed
+to learn() by all ranks / wall time; GAE steps/s is reported beside it.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): every rank owns its own
+N_envs env shard (weak scaling) and the only collective is the flat-gradient all-reduce.
+
+Rank 0 prints ONE JSON line.  `roofline` is the GAE kernel (HBM-bound), timed with events on
+the stream it is launched on; `kernels` carries the same figures for the replay gather
+kernels on BASELINE configs 3 and 4 shaped data; `cpu_baseline` is the oracle's port of the
+reference path (per-env Python GAE loop + torch-CPU learn) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from torchrl_amd import functional as F  # noqa: E402
+from torchrl_amd.contrib.controllers import PPOController, DDPGController, DQNController  # noqa: E402
+from torchrl_amd.utils.storage import TensorTupleDataset  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=None)
+  ap.add_argument('--warmup', type=int, default=None)
+  ap.add_argument('--workload', default='ppo', choices=['ppo', 'ddpg', 'dqn_atari'])
+  ap.add_argument('--T', type=int, default=2048)
+  ap.add_argument('--N', type=int, default=4096)
+  ap.add_argument('--hidden', default='64,64')
+  ap.add_argument('--minibatch', type=int, default=None)
+  ap.add_argument('--epochs', type=int, default=4)
+  ap.add_argument('--capacity', type=int, default=None)
+  ap.add_argument('--kernel-iters', type=int, default=50)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extras', action='store_true')
+  return ap.parse_args()
+
+
+def setup_dist(args):
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  torch.cuda.set_device(local)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+  if args.gpus != world and rank == 0:
+    print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+  return rank, local, world
+
+
+def barrier(world):
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+
+
+def timed_steps(step_fn, steps, warmup, world):
+  for _ in range(warmup):
+    step_fn()
+  barrier(world)
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step_fn()
+  barrier(world)
+  dt = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+  return dt
+
+
+def kernel_time_us(launch, iters):
+  """Average duration of one launch, HIP events on torch's current stream (the stream the
+  C ABI launches on)."""
+  for _ in range(3):
+    launch()
+  torch.cuda.synchronize()
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  a.record()
+  for _ in range(iters):
+    launch()
+  b.record()
+  torch.cuda.synchronize()
+  return a.elapsed_time(b) * 1e3 / iters
+
+
+def roofline(name, algo_bytes, us, note):
+  gbs = algo_bytes / (us * 1e-6) / 1e9
+  return {'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+          'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'us_per_launch': round(us, 2),
+          'algorithmic_bytes_per_launch': int(algo_bytes), 'note': note}
+
+
+# ------------------------------------------------------------------------------ PPO (configs[1])
+def make_rollout(T, N, obs_size, act_size, dev, seed):
+  g = torch.Generator(device=dev).manual_seed(seed)
+  obs = torch.randn(T, N, obs_size, device=dev, generator=g)
+  action = torch.randn(T, N, act_size, device=dev, generator=g)
+  reward = torch.randn(T, N, device=dev, generator=g)
+  done = (torch.rand(T, N, device=dev, generator=g) < 0.01).float()
+  last_next_obs = torch.randn(N, obs_size, device=dev, generator=g)
+  return obs, action, reward, done, last_next_obs
+
+
+def bench_ppo(args, rank, world, dev):
+  T, N, obs_size, act_size = args.T, args.N, 3, 1
+  hidden = tuple(int(h) for h in args.hidden.split(','))
+  B = args.minibatch or 65536
+  steps = args.steps if args.steps is not None else 5
+  warmup = args.warmup if args.warmup is not None else 1
+  torch.manual_seed(0)
+  ctl = PPOController(obs_size, act_size, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3,
+                      clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden)
+  obs, action, reward, done, last_next_obs = make_rollout(T, N, obs_size, act_size, dev, 1234 + rank)
+  last_done = done[-1]
+  n = T * N
+  phase = {}
+
+  def step():
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e2 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    returns, adv, logp, _values = ctl.compute_return_batched(obs, action, reward, last_next_obs, last_done,
+                                                             env_major_out=True)
+    # minibatches in the reference's env-major order (examples/ppo.py:61-68)
+    obs_em = obs.transpose(0, 1).reshape(n, obs_size)
+    act_em = action.transpose(0, 1).reshape(n, act_size)
+    logp_em = logp.transpose(0, 1).reshape(n, act_size)
+    ret_em, adv_em = returns.reshape(n, 1), adv.reshape(n, 1)
+    e1.record()
+    for _ in range(args.epochs):
+      for s in range(0, n, B):
+        e = min(n, s + B)
+        ctl.learn(obs_em[s:e], act_em[s:e], None, None, None, ret_em[s:e], logp_em[s:e], adv_em[s:e])
+    e2.record()
+    phase['ev'] = (e0, e1, e2)
+
+  dt = timed_steps(step, steps, warmup, world)
+  e0, e1, e2 = phase['ev']
+  ms_return, ms_learn = e0.elapsed_time(e1), e1.elapsed_time(e2)
+  learned = args.epochs * n * steps * world
+  value = learned / dt
+
+  # --- GAE kernel alone: events around launches on its own stream, caller-owned outputs
+  values = torch.randn(T, N, device=dev)
+  boot = torch.randn(N, device=dev)
+  out = (torch.empty(T, N, device=dev), torch.empty(T, N, device=dev))
+  us = kernel_time_us(lambda: F.gae(reward, values, boot, 0.99, 0.95, out=out), args.kernel_iters)
+  algo = 16 * n + 4 * N          # r, v read + ret, adv written (4 B each) + bootstrap row
+  roof = roofline('k_gae_tiled', algo, us, '16 B per (t, env) step x T*N = %d steps per launch' % n)
+  extra = {'gae_steps_per_sec_kernel': round(n / (us * 1e-6), 1),
+           'gae_steps_per_sec_compute_return': round(n / (ms_return * 1e-3), 1),
+           'ms_compute_return': round(ms_return, 3), 'ms_learn_epochs': round(ms_learn, 3)}
+  res = {
+      'metric': 'learner transitions/sec (PPO: GAE + clipped loss + update)', 'value': round(value, 1),
+      'unit': 'transitions/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+      'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+      'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': 'ppo_gae_clip: T=%d, N_envs=%d per GPU, MLP %s, obs 3, act 1' % (T, N, args.hidden),
+                 'minibatch': B, 'n_epochs': args.epochs, 'learn_calls_per_step': args.epochs * ((n + B - 1) // B),
+                 'gamma': 0.99, 'lmbda': 0.95, 'clip_ratio': 0.2, 'parallelism': 'dp%d' % world},
+      'roofline': roof,
+  }
+  res.update(extra)
+  return res, dict(T=T, hidden=hidden, B=B, epochs=args.epochs)
+
+
+def cpu_baseline_ppo(info):
+  """Oracle port of the reference path on the host: per-env compute_return loop
+  (ppo_controller.py:32-51) + learn() minibatches (ppo_controller.py:53-80)."""
+  from oracle import loss_oracle
+  from torchrl_amd.contrib.models import ActorCriticNet
+  torch.set_num_threads(1)
+  T, hidden, B, epochs = info['T'], info['hidden'], info['B'], info['epochs']
+  n_envs = 32
+  torch.manual_seed(0)
+  net = ActorCriticNet(3, 1, hidden)
+  opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+  cols = [[] for _ in range(8)]
+  t0 = time.perf_counter()
+  for _ in range(n_envs):
+    obs, act = torch.randn(T, 3), torch.randn(T, 1)
+    rew, nobs, done = torch.randn(T, 1), torch.randn(T, 3), torch.zeros(T, 1)
+    ret, lp, v = loss_oracle.ppo_compute_return(net, obs, act, rew, nobs, done, 0.99, 0.95)
+    for c, x in zip(cols, (obs, act, rew, nobs, done, ret, lp, ret - v)):
+      c.append(x)
+  cols = [torch.cat(c, 0) for c in cols]
+  n = n_envs * T
+  Bc = min(B, n)
+  for _ in range(epochs):
+    for s in range(0, n, Bc):
+      loss_oracle.ppo_learn(net, opt, *[c[s:s + Bc] for c in cols], clip=0.2, alpha=0.5, beta=1e-3,
+                            max_grad_norm=1.0)
+  dt = time.perf_counter() - t0
+  return {'value': round(epochs * n / dt, 1), 'unit': 'transitions/s', 'cores': 1, 'kind': 'port',
+          'sample': '%d of the envs x T=%d: per-env torch-CPU GAE loop + %d epochs x minibatch %d learn(), '
+                    '1 thread (the reference loops are single-threaded Python); %.1f s' % (n_envs, T, epochs, Bc, dt),
+          'host_cpus': os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------ replay gathers
+def fill_ring(ds, n_rows, make_cols, chunk):
+  for lo in range(0, n_rows, chunk):
+    ds.extend(*make_cols(min(chunk, n_rows - lo)))
+
+
+def gather_roofline(dev, iters, rows, B, atari):
+  """Gather kernel(s) alone on BASELINE config 3 (Pendulum, 36 B rows) or 4 (Atari u8 frames)."""
+  g = torch.Generator(device=dev).manual_seed(7)
+  if atari:
+    ds = TensorTupleDataset(size=rows, device=dev,
+                            storage_dtypes=[torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32],
+                            gather_dtypes=[torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32])
+    def cols(k):
+      return [torch.randint(0, 256, (k, 84, 84, 4), device=dev, dtype=torch.uint8, generator=g),
+              torch.randint(0, 6, (k, 1), device=dev, generator=g).float(),
+              torch.randint(-1, 2, (k, 1), device=dev, generator=g).float(),
+              torch.randint(0, 256, (k, 84, 84, 4), device=dev, dtype=torch.uint8, generator=g),
+              (torch.rand(k, 1, device=dev, generator=g) < 0.005).float()]
+    fill_ring(ds, rows, cols, 4096)
+    row_bytes = 2 * 28224 + 12
+  else:
+    ds = TensorTupleDataset(size=rows, device=dev)
+    def cols(k):
+      return [torch.rand(k, 3, device=dev, generator=g) * 2 - 1, torch.rand(k, 1, device=dev, generator=g) * 2 - 1,
+              -16 * torch.rand(k, 1, device=dev, generator=g), torch.rand(k, 3, device=dev, generator=g) * 2 - 1,
+              (torch.rand(k, 1, device=dev, generator=g) < 0.01).float()]
+    fill_ring(ds, rows, cols, 1 << 18)
+    row_bytes = 36
+  idx = torch.randint(0, rows, (B,), device=dev, generator=g)
+  us = kernel_time_us(lambda: ds._gather_index(idx), iters)
+  algo = B * (2 * row_bytes + 8)
+  name = 'k_gather_wide+k_gather_narrow' if atari else 'k_gather_narrow'
+  r = roofline(name, algo, us, '(2 x %d B row + 8 B index) x B=%d rows gathered from a %d-row ring (%.1f GB)'
+               % (row_bytes, B, rows, rows * ds.row_bytes / 1e9))
+  r['transitions_per_sec'] = round(B / (us * 1e-6), 1)
+  del ds
+  torch.cuda.empty_cache()
+  return r
+
+
+# ------------------------------------------------------------------------------ DDPG / DQN learner loops
+def bench_offpolicy(args, rank, world, dev, atari):
+  steps = args.steps if args.steps is not None else 200
+  warmup = args.warmup if args.warmup is not None else 20
+  g = torch.Generator(device=dev).manual_seed(100 + rank)
+  torch.manual_seed(0)
+  if atari:
+    cap = args.capacity or 1_000_000
+    B = args.minibatch or 256
+    ds = TensorTupleDataset(size=cap, device=dev,
+                            storage_dtypes=[torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32])
+    def cols(k):
+      return [torch.randint(0, 256, (k, 28224), device=dev, dtype=torch.uint8, generator=g),
+              torch.randint(0, 6, (k, 1), device=dev, generator=g).float(),
+              torch.randint(-1, 2, (k, 1), device=dev, generator=g).float(),
+              torch.randint(0, 256, (k, 28224), device=dev, dtype=torch.uint8, generator=g),
+              (torch.rand(k, 1, device=dev, generator=g) < 0.005).float()]
+    fill_ring(ds, cap, cols, 8192)
+    ctl = DQNController(28224, 6, double_dqn=True, gamma=0.99, lr=1e-3, n_update_interval=10, device=dev)
+    row_bytes, name = 2 * 28224 + 12, 'double_dqn_atari'
+    wl = 'double_dqn: %d-row replay of 84x84x4 u8 frames per GPU (%.0f GB), flat-frame QNet 28224-128-128-6' % (
+        cap, cap * ds.row_bytes / 1e9)
+  else:
+    cap = args.capacity or 1_000_000
+    B = args.minibatch or 128
+    ds = TensorTupleDataset(size=cap, device=dev)
+    def cols(k):
+      return [torch.rand(k, 3, device=dev, generator=g) * 2 - 1, torch.rand(k, 1, device=dev, generator=g) * 2 - 1,
+              -16 * torch.rand(k, 1, device=dev, generator=g), torch.rand(k, 3, device=dev, generator=g) * 2 - 1,
+              (torch.rand(k, 1, device=dev, generator=g) < 0.01).float()]
+    fill_ring(ds, cap, cols, 1 << 18)
+    ctl = DDPGController(3, 1, -2.0, 2.0, actor_lr=1e-4, critic_lr=1e-3, gamma=0.99, tau=1e-2, device=dev)
+    row_bytes, name = 36, 'ddpg_pendulum'
+    wl = 'ddpg: %d-row Pendulum-shaped f32 replay per GPU, actor/critic MLP 256x256' % cap
+
+  def step():
+    ctl.learn(*ds.sample(B))     # MT19937 randperm-prefix (host) + HIP gather + fused loss/update
+
+  dt = timed_steps(step, steps, warmup, world)
+  value = B * steps * world / dt
+  idx = torch.randint(0, cap, (B,), device=dev, generator=g)
+  us = kernel_time_us(lambda: ds._gather_index(idx), args.kernel_iters)
+  roof = roofline('k_gather_wide+k_gather_narrow' if atari else 'k_gather_narrow', B * (2 * row_bytes + 8), us,
+                  '(2 x %d B + 8 B) x B=%d' % (row_bytes, B))
+  res = {
+      'metric': 'learner transitions/sec (sample+loss+update)', 'value': round(value, 1), 'unit': 'transitions/s',
+      'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix (bit-exact)',
+                 'parallelism': 'dp%d' % world, 'name': name},
+      'roofline': roof,
+  }
+  return res, dict(cap=cap, B=B, atari=atari)
+
+
+def cpu_baseline_offpolicy(info):
+  """Reference path on the host (examples/dqn.py:40-42): torch.randperm(n)[:B], fancy-index
+  gather of float32 columns, learn() on torch-CPU."""
+  from oracle import loss_oracle
+  from torchrl_amd.contrib import models
+  torch.set_num_threads(1)
+  B, atari = info['B'], info['atari']
+  torch.manual_seed(0)
+  if atari:
+    n = 20_000        # float32 frames as the reference stores them: 20k rows = 4.5 GB
+    colsz = [28224, 1, 1, 28224, 1]
+  else:
+    n = info['cap']
+    colsz = [3, 1, 1, 3, 1]
+  cols = [torch.rand(n, w) for w in colsz]
+  cols[1] = torch.randint(0, 6, (n, 1)).float() if atari else cols[1]
+  cols[4] = (torch.rand(n, 1) < 0.01).float()
+  if atari:
+    q, tq = models.QNet(28224, 6), models.QNet(28224, 6)
+    opt = torch.optim.Adam(q.parameters(), lr=1e-3)
+    fn = lambda b: loss_oracle.dqn_learn(q, tq, opt, *b, gamma=0.99, double_dqn=True)
+  else:
+    a, ta = models.DDPGActorNet(3, 1, 256), models.DDPGActorNet(3, 1, 256)
+    c, tc = models.DDPGCriticNet(3, 1, 256), models.DDPGCriticNet(3, 1, 256)
+    ao, co = torch.optim.Adam(a.parameters(), lr=1e-4), torch.optim.Adam(c.parameters(), lr=1e-3)
+    fn = lambda b: loss_oracle.ddpg_learn(a, c, ta, tc, ao, co, *b, gamma=0.99, tau=1e-2)
+  iters, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < 10.0:
+    idx = torch.randperm(n)[:B]
+    fn([x[idx] for x in cols])
+    iters += 1
+  dt = time.perf_counter() - t0
+  return {'value': round(iters * B / dt, 1), 'unit': 'transitions/s', 'cores': 1, 'kind': 'port',
+          'sample': '%d train() steps in %.1f s: torch.randperm(%d)[:%d] + fancy-index + learn() on torch-CPU, 1 thread'
+                    % (iters, dt, n, B), 'host_cpus': os.cpu_count()}
+
+
+def main():
+  args = parse()
+  rank, local, world = setup_dist(args)
+  dev = torch.device('cuda', local)
+  if args.workload == 'ppo':
+    res, info = bench_ppo(args, rank, world, dev)
+  else:
+    res, info = bench_offpolicy(args, rank, world, dev, atari=args.workload == 'dqn_atari')
+  if rank == 0 and world == 1:
+    if args.workload == 'ppo' and not args.no_extras:
+      res['kernels'] = [
+          gather_roofline(dev, args.kernel_iters, 1_000_000, 65536, atari=False),
+          gather_roofline(dev, args.kernel_iters, 1_000_000, 128, atari=False),
+          gather_roofline(dev, args.kernel_iters, 200_000, 1024, atari=True),
+          gather_roofline(dev, args.kernel_iters, 200_000, 256, atari=True),
+      ]
+    if not args.no_cpu_baseline:
+      res['cpu_baseline'] = cpu_baseline_ppo(info) if args.workload == 'ppo' else cpu_baseline_offpolicy(info)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+  main()

@@ -10,18 +10,27 @@
 //   ret   = gae + v[t];   adv = ret - v[t]
 // which is the reference's op order, so returns/advantages are bit-identical to it.
 //
-// Structure: a workgroup owns EPB consecutive envs and walks T backwards in tiles of TT
-// rows.  The recurrence is serial in t, so the work is split by role:
-//   - all lanes:   load the reward/value tile (coalesced along the env axis), form delta
-//                  off the dependent chain and stage it in LDS;
-//   - EPB lanes:   run the chain  gae = delta + c * gae  over the tile out of LDS
+// Structure: a workgroup owns E consecutive envs and walks T backwards in tiles of TT rows.
+// The recurrence is serial in t, so the work is split by role:
+//   - mover lanes: load the reward/value tile (16 B per lane, coalesced along the env axis),
+//                  form delta off the dependent chain and stage delta and v in LDS;
+//   - E lanes:     run the chain  gae = delta + c * gae  over the tile out of LDS
 //                  (2 dependent VALU ops per step), writing gae back in place;
-//   - all lanes:   ret/adv from gae and the staged value tile, coalesced stores.
-// HBM traffic is the algorithmic minimum: r and v read once (plus one halo row of v per
-// tile), ret and adv written once = 16 B per (t, env) step.
+//   - mover lanes: ret/adv from gae and the staged value tile, 16 B stores.
+// k_gae_pipe (the fast path) gives each role waves of its own and software-pipelines them
+// over LDS rings: at stage s two DMA waves stream tile s+PF straight into LDS, the worker
+// waves stage tile s and write out tile s-2, and the chain wave scans tile s-1; one barrier
+// per stage.  k_gae_tiled is the plain, unpipelined form for what the fast path does not
+// take (N % 4 != 0, unaligned bases, the masked extension).
+// HBM traffic is the algorithmic minimum: r and v read once (the v[t+1] operand re-reads the
+// same lines through L1/L2), ret and adv written once = 16 B per (t, env) step.
+#include <stdlib.h>
+
 #include "trl_common.h"
 
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int EPB, bool MASKED>
 __global__ __launch_bounds__(256) void k_gae_tiled(const float *__restrict__ reward,
@@ -94,6 +103,289 @@ __global__ __launch_bounds__(256) void k_gae_tiled(const float *__restrict__ rew
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Pipelined kernel (reference mode).  Block = 448 lanes = 7 waves in three roles:
+//   wave 0      chain    E active lanes scan tile s-1 out of LDS
+//   waves 1-2   DMA      stream tile s+PF of reward and value HBM -> LDS with LDS-DMA
+//                        (global_load_lds, 16 B per lane, 1 KiB per instruction, no VGPRs),
+//                        PF tiles in flight; nothing else sits in these waves' vector-memory
+//                        queue, so one counted s_waitcnt vmcnt retires exactly the tile the
+//                        workers read next.  Loads are never predicated (clamped addresses),
+//                        which keeps the instruction count per stage fixed.
+//   waves 3-6   workers  tile s: delta from the raw planes -> padded scan buffers;
+//                        tile s-2: ret = gae + v, adv = ret - v, 16 B stores
+// One barrier per stage.  A tile is TT = 2048 / E rows = 8 KiB per f32 plane.
+// LDS-DMA visibility rule (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the
+// wait that retires it"): the DMA waves wait for tile s+1 at the END of stage s, before the
+// barrier; the workers read it in stage s+1.
+template <int E, int PF>
+__global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ reward,
+                                                  const float *__restrict__ value,
+                                                  const float *__restrict__ bootstrap, int T, int N,
+                                                  float gamma, float gl, int out_nt, int ngroups,
+                                                  float *__restrict__ returns,
+                                                  float *__restrict__ adv, int dbg) {
+  // dbg: ablation switches for tools/gae_sweep.py (0 in production): 1 = no chain,
+  // 2 = no output stores, 4 = no staging pass, 8 = no DMA
+  constexpr int QPR = E / 4;        // quads (float4) per tile row
+  constexpr int RPU = 256 / QPR;    // rows covered by one pass of the 256 worker lanes
+  constexpr int TT = 2 * RPU;       // rows per tile
+  constexpr int PLANE = TT * E;     // 2048 floats
+  constexpr int LD = E + 1;         // row stride of the staged value tile [t][env] (odd: the env-major
+                                    // writer's column reads spread over the banks)
+  constexpr int TTP = TT + 4;       // row stride of the scan buffer, which is TRANSPOSED: [env][t], so
+                                    // that a chain lane reads/writes 4 steps per ds_read/write_b128;
+                                    // TTP % 64 == 4 (E 16, 32) or 36 (E 64) keeps 16 lanes on 16 bank quads
+  constexpr int NS = 3;             // scan ring: staged / being scanned / being written out
+  constexpr int NR = PF + 2;        // raw ring: PF in flight + being read + halo of the previous tile
+  constexpr int RPI = 256 / E;      // rows one 1 KiB DMA instruction covers
+  // one array: see cdna_hip_programming.md on a second __shared__ object beside a DMA ring
+  __shared__ __attribute__((aligned(16))) float lds[NR * 2 * PLANE + NS * (E * TTP + TT * LD)];
+  float *s_raw = lds;                               // [NR][2][PLANE]  (reward plane, value plane)
+  float *s_d = lds + NR * 2 * PLANE;                // [NS][E][TTP]    delta -> gae in place
+  float *s_v = s_d + NS * E * TTP;                  // [NS][TT][LD]
+
+  // XCD-aware group order: blocks b and b + 8 share an XCD (its L2), so give each XCD a
+  // contiguous run of env groups; neighbours that share a 128 B line then share an L2.
+  int grp = blockIdx.x;
+  if ((ngroups & 7) == 0) grp = (blockIdx.x & 7) * (ngroups >> 3) + (blockIdx.x >> 3);
+  const int env0 = grp * E;
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int ntiles = (T + TT - 1) / TT;
+  const int nstages = ntiles + 2;
+  // tile j (j = 0 is the LAST TT rows) covers t in [t_lo(j), t_hi(j))
+  auto t_hi = [&](int j) { return T - j * TT; };
+  auto t_lo = [&](int j) { const int lo = T - (j + 1) * TT; return lo < 0 ? 0 : lo; };
+
+  if (wave == 1 || wave == 2) {
+    // ================================================================== DMA waves
+    const int dw = wave - 1;                       // owns instructions [dw*4, dw*4+4) of each plane
+    const int q = lane % QPR, rsub = lane / QPR;
+    int envq = env0 + 4 * q;
+    envq = envq < N ? envq : 0;                    // clamped: always a valid quad
+    auto issue = [&](int j) {
+      const int jc = j < ntiles ? j : ntiles - 1;
+      const int lo = t_lo(jc), hi = t_hi(jc);
+      float *slot = s_raw + (j % NR) * 2 * PLANE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ins = dw * 4 + i;
+        int t = lo + ins * RPI + rsub;
+        t = t < hi ? t : hi - 1;
+        const int64_t g = (int64_t)t * N + envq;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reward + g),
+                                         (__attribute__((address_space(3))) void *)(slot + ins * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(value + g),
+                                         (__attribute__((address_space(3))) void *)(slot + PLANE + ins * 256), 16,
+                                         0, 0);
+      }
+    };
+    static_assert(PF >= 1 && PF <= 4, "prefetch depth");
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (!(dbg & 8)) issue(j);
+    // tile 0 landed (8 loads per tile per wave; PF - 1 younger tiles may stay in flight)
+    if (PF == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PF == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (PF == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (PF == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nstages; ++s) {
+      if (!(dbg & 8)) issue(s + PF);
+      // tile s + 1 landed; tiles s+2 .. s+PF stay in flight across the barrier
+      if (PF == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (PF == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (PF == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (PF == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain before the LDS is released
+  } else if (wave >= 3) {
+    // ================================================================== workers
+    const int m = (int)threadIdx.x - 192;            // [0, 256)
+    const int q = m % QPR, row0 = m / QPR;
+    const int envq = env0 + 4 * q;
+    const bool qlive = envq < N;
+    float4 boot4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qlive) boot4 = *(const float4 *)(bootstrap + envq);
+    __syncthreads();                                 // pairs with the DMA waves' prologue barrier
+    for (int s = 0; s < nstages; ++s) {
+      if (s < ntiles && !(dbg & 4)) {   // ---- stage tile s: delta and v into the padded scan buffers
+        const int lo = t_lo(s), rows = t_hi(s) - lo;
+        const float *raw_r = s_raw + (s % NR) * 2 * PLANE, *raw_v = raw_r + PLANE;
+        const float *halo = s_raw + ((s + NR - 1) % NR) * 2 * PLANE + PLANE;   // tile s-1, row 0
+        float *sd = s_d + (s % NS) * E * TTP, *sv = s_v + (s % NS) * TT * LD;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int tl = row0 + u * RPU;
+          if (tl < rows) {
+            const float4 r = *(const float4 *)(raw_r + tl * E + 4 * q);
+            const float4 v = *(const float4 *)(raw_v + tl * E + 4 * q);
+            float4 n;
+            if (tl + 1 < rows) n = *(const float4 *)(raw_v + (tl + 1) * E + 4 * q);
+            else if (s > 0) n = *(const float4 *)(halo + 4 * q);
+            else n = boot4;
+            const float r4[4] = {r.x, r.y, r.z, r.w}, v4[4] = {v.x, v.y, v.z, v.w};
+            const float n4[4] = {n.x, n.y, n.z, n.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              sd[(4 * q + c) * TTP + tl] = __fsub_rn(__fadd_rn(r4[c], __fmul_rn(gamma, n4[c])), v4[c]);
+              sv[tl * LD + 4 * q + c] = v4[c];
+            }
+          }
+        }
+      }
+      const int jo = s - 2;   // ---- write out tile s-2
+      if (jo >= 0 && jo < ntiles && !(dbg & 2)) {
+        const int lo = t_lo(jo), hi = t_hi(jo);
+        const float *sd = s_d + (jo % NS) * E * TTP, *sv = s_v + (jo % NS) * TT * LD;
+        if (!out_nt) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int tl = row0 + u * RPU;
+            if (qlive && lo + tl < hi) {
+              float rt[4], ad[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float v = sv[tl * LD + 4 * q + c];
+                rt[c] = __fadd_rn(sd[(4 * q + c) * TTP + tl], v);
+                ad[c] = __fsub_rn(rt[c], v);
+              }
+              const int64_t g = (int64_t)(lo + tl) * N + envq;
+              *(float4 *)(returns + g) = make_float4(rt[0], rt[1], rt[2], rt[3]);
+              if (adv) *(float4 *)(adv + g) = make_float4(ad[0], ad[1], ad[2], ad[3]);
+            }
+          }
+        } else {
+          // env-major output: a lane takes 4 consecutive t of one env -> one 16 B store
+          constexpr int TQ = TT / 4;  // t-quads per env per tile; E * TQ == 512
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int i = m + u * 256;
+            const int e = i / TQ, tq = i % TQ;
+            const int tl = 4 * tq, t = lo + tl;
+            if (env0 + e < N && t < hi) {
+              float rt[4], ad[4];
+              const float4 g4 = *(const float4 *)(sd + e * TTP + tl);
+              const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float v = sv[(tl + c) * LD + e];
+                rt[c] = __fadd_rn(gq[c], v);
+                ad[c] = __fsub_rn(rt[c], v);
+              }
+              const int64_t g = (int64_t)(env0 + e) * T + t;
+              if (t + 4 <= hi && (g & 3) == 0) {
+                *(float4 *)(returns + g) = make_float4(rt[0], rt[1], rt[2], rt[3]);
+                if (adv) *(float4 *)(adv + g) = make_float4(ad[0], ad[1], ad[2], ad[3]);
+              } else {
+                for (int c = 0; c < 4 && t + c < hi; ++c) {
+                  returns[g + c] = rt[c];
+                  if (adv) adv[g + c] = ad[c];
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // ================================================================== chain wave
+    float gae = 0.0f;
+    __builtin_amdgcn_s_setprio(3);                   // the serial chain is the critical path: win issue arbitration
+    __syncthreads();                                 // prologue barrier
+    for (int s = 0; s < nstages; ++s) {
+      const int jc = s - 1;
+      if (jc >= 0 && jc < ntiles && lane < E && !(dbg & 1)) {
+        const int rows = t_hi(jc) - t_lo(jc);
+        float *sd = s_d + (jc % NS) * E * TTP + lane * TTP;   // this env's row of the transposed tile
+        int top = rows;
+        for (; top & 7; --top) {   // ragged head of a partial tile, one step at a time
+          gae = __fadd_rn(sd[top - 1], __fmul_rn(gl, gae));
+          sd[top - 1] = gae;
+        }
+        // Full groups of 8 steps, branch-free, two register sets in ping-pong: the next group's
+        // deltas are fetched from LDS (2 x ds_read_b128) while the current group runs down the
+        // dependent chain (2 VALU ops per step) and goes back as 2 x ds_write_b128.
+        auto fetch = [&](f32x4 (&d)[2], int g) {
+          d[0] = *(const f32x4 *)(sd + g);
+          d[1] = *(const f32x4 *)(sd + g + 4);
+        };
+        auto run = [&](const f32x4 (&d)[2], int g) {
+          f32x4 lo4, hi4;   // one IR vector store each, so they stay ds_write_b128
+          hi4[3] = gae = __fadd_rn(d[1][3], __fmul_rn(gl, gae));
+          hi4[2] = gae = __fadd_rn(d[1][2], __fmul_rn(gl, gae));
+          hi4[1] = gae = __fadd_rn(d[1][1], __fmul_rn(gl, gae));
+          hi4[0] = gae = __fadd_rn(d[1][0], __fmul_rn(gl, gae));
+          lo4[3] = gae = __fadd_rn(d[0][3], __fmul_rn(gl, gae));
+          lo4[2] = gae = __fadd_rn(d[0][2], __fmul_rn(gl, gae));
+          lo4[1] = gae = __fadd_rn(d[0][1], __fmul_rn(gl, gae));
+          lo4[0] = gae = __fadd_rn(d[0][0], __fmul_rn(gl, gae));
+          *(f32x4 *)(sd + g + 4) = hi4;
+          *(f32x4 *)(sd + g) = lo4;
+        };
+        if (rows == TT) {
+          // full tile: straight-line code, no loop bookkeeping on the chain's issue slots;
+          // three register sets rotate so that each fetch is two groups ahead of its use
+          constexpr int NG = TT / 8;
+          f32x4 d[3][2];
+          fetch(d[0], TT - 8);
+          if (NG > 1) fetch(d[1], TT - 16);
+#pragma unroll
+          for (int k = 0; k < NG; ++k) {
+            if (k + 2 < NG) fetch(d[(k + 2) % 3], TT - 8 * (k + 3));
+            run(d[k % 3], TT - 8 * (k + 1));
+          }
+        } else {
+          f32x4 da[2], db[2];
+          int g = top - 8;                       // top is a multiple of 8 here
+          if (g >= 0) fetch(da, g);
+          while (g >= 0) {
+            fetch(db, g >= 8 ? g - 8 : 0);       // clamped: the last prefetch is discarded
+            run(da, g);
+            g -= 8;
+            if (g < 0) break;
+            fetch(da, g >= 8 ? g - 8 : 0);
+            run(db, g);
+            g -= 8;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int E, int PF>
+int launch_pipe(const float *reward, const float *value, const float *bootstrap, int T, int N, float gamma,
+                float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
+  const int ngroups = (int)trl_cdiv(N, E);
+  hipLaunchKernelGGL((k_gae_pipe<E, PF>), dim3(ngroups), dim3(448), 0, st, reward, value, bootstrap, T, N, gamma,
+                     gl, out_nt, ngroups, returns, adv, dbg);
+  TRL_CHECK_LAUNCH("trl_gae_reverse_scan");
+  return TRL_OK;
+}
+
+// E and PF as run-time choices (0 = default heuristic); used by the dispatcher and the sweep tool
+int dispatch_pipe(int E, int PF, const float *reward, const float *value, const float *bootstrap, int T, int N,
+                  float gamma, float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
+  if (E == 0) E = N > 256 * 32 ? 64 : (N > 256 * 16 ? 32 : 16);
+  if (PF == 0) PF = 3;
+#define TRL_PIPE_CASE(e, pf)  \
+  if (E == e && PF == pf)     \
+    return launch_pipe<e, pf>(reward, value, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
+  TRL_PIPE_CASE(16, 2) TRL_PIPE_CASE(16, 3) TRL_PIPE_CASE(16, 4)
+  TRL_PIPE_CASE(32, 2) TRL_PIPE_CASE(32, 3) TRL_PIPE_CASE(32, 4)
+  TRL_PIPE_CASE(64, 2) TRL_PIPE_CASE(64, 3) TRL_PIPE_CASE(64, 4)
+#undef TRL_PIPE_CASE
+  trl_set_error("trl_gae: unsupported tuning E=%d PF=%d", E, PF);
+  return TRL_EINVAL;
+}
+
 template <int EPB>
 int launch(bool masked, const float *reward, const float *value, const float *done,
            const float *bootstrap, int T, int N, float gamma, float gl, int out_nt, float *returns,
@@ -128,14 +420,17 @@ extern "C" int trl_gae_reverse_scan(const float *reward, const float *value, con
   if (T == 0 || N == 0) return TRL_OK;
   hipStream_t st = (hipStream_t)stream;
   const bool masked = mode == TRL_GAE_MASKED;
-  // Envs per workgroup: as many as still leave >= 256 workgroups (one per CU), floor 16
-  // (a 64 B row segment).
-  if (N >= 256 * 64)
-    return launch<64>(masked, reward, value, done, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
-                      out_layout, returns, adv, st);
-  if (N >= 256 * 32)
-    return launch<32>(masked, reward, value, done, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
-                      out_layout, returns, adv, st);
+  const bool aligned = N % 4 == 0 && ((uintptr_t)reward % 16 == 0) && ((uintptr_t)value % 16 == 0) &&
+                       ((uintptr_t)bootstrap % 16 == 0) && ((uintptr_t)returns % 16 == 0) &&
+                       (adv == nullptr || (uintptr_t)adv % 16 == 0);
+  if (aligned && !masked) {
+    // Envs per workgroup: 16 (a 64 B row segment) while that gives at most one workgroup per
+    // CU (the pipelined kernel holds most of a CU's LDS), then wider segments.
+    int E = 0, PF = 0, dbg = 0;
+    if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d", &E, &PF, &dbg);   // tools/gae_sweep.py
+    return dispatch_pipe(E, PF, reward, value, bootstrap, (int)T, (int)N, gamma, gamma_lambda, out_layout,
+                         returns, adv, dbg, st);
+  }
   return launch<16>(masked, reward, value, done, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
                     out_layout, returns, adv, st);
 }
