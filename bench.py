@@ -93,15 +93,22 @@ def timed_steps(step_fn, steps, warmup, world):
 
 
 def kernel_time_us(launch, iters):
-  """Average duration of one launch, HIP events on torch's current stream (the stream the
-  C ABI launches on)."""
+  """Average duration of one launch.  `iters` launches are captured into one HIP graph on the
+  stream the C ABI launches on (torch's current stream during capture) and the replay is
+  bracketed by events on that same stream, so host launch cost (ctypes, Python) is not in
+  the figure; kernels of a few microseconds would otherwise be timed at the host's rate."""
   for _ in range(3):
     launch()
   torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    for _ in range(iters):
+      launch()
+  g.replay()
+  torch.cuda.synchronize()
   a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   a.record()
-  for _ in range(iters):
-    launch()
+  g.replay()
   b.record()
   torch.cuda.synchronize()
   return a.elapsed_time(b) * 1e3 / iters
@@ -251,7 +258,8 @@ def gather_roofline(dev, iters, rows, B, atari):
     fill_ring(ds, rows, cols, 1 << 18)
     row_bytes = 36
   idx = torch.randint(0, rows, (B,), device=dev, generator=g)
-  us = kernel_time_us(lambda: ds._gather_index(idx), iters)
+  out = ds._alloc_out(B)
+  us = kernel_time_us(lambda: ds._gather_index(idx, out), iters)
   algo = B * (2 * row_bytes + 8)
   name = 'k_gather_wide+k_gather_narrow' if atari else 'k_gather_narrow'
   r = roofline(name, algo, us, '(2 x %d B row + 8 B index) x B=%d rows gathered from a %d-row ring (%.1f GB)'
@@ -303,7 +311,8 @@ def bench_offpolicy(args, rank, world, dev, atari):
   dt = timed_steps(step, steps, warmup, world)
   value = B * steps * world / dt
   idx = torch.randint(0, cap, (B,), device=dev, generator=g)
-  us = kernel_time_us(lambda: ds._gather_index(idx), args.kernel_iters)
+  out = ds._alloc_out(B)
+  us = kernel_time_us(lambda: ds._gather_index(idx, out), args.kernel_iters)
   roof = roofline('k_gather_wide+k_gather_narrow' if atari else 'k_gather_narrow', B * (2 * row_bytes + 8), us,
                   '(2 x %d B + 8 B) x B=%d' % (row_bytes, B))
   res = {

@@ -13,6 +13,50 @@ from torch import nn
 from torch.distributions import Normal, Categorical
 
 
+class _SplitKLinearFn(torch.autograd.Function):
+  """y = x W^T + b with a weight gradient that PyTorch-ROCm computes efficiently.
+
+  dW[out, in] = dY[B, out]^T X[B, in] is a skinny GEMM whose reduction dimension is the batch.
+  For B in the tens of thousands the BLAS picks a kernel without split-K and one workgroup
+  walks the whole batch (measured on MI355X, B = 65536, 64x64: 187 us, against 17 us for
+  the same product as a batched matmul over 64 slabs of the batch plus a sum).  Same
+  arithmetic up to the order of the fp32 additions."""
+
+  @staticmethod
+  def forward(ctx, x, weight, bias):
+    ctx.save_for_backward(x, weight)
+    return torch.addmm(bias, x, weight.t())
+
+  @staticmethod
+  def backward(ctx, gy):
+    x, weight = ctx.saved_tensors
+    gy = gy.contiguous()
+    B, n_out = gy.shape
+    gx = gy @ weight if ctx.needs_input_grad[0] else None
+    slabs = 64
+    while slabs > 1 and (B % slabs or B // slabs < 256):
+      slabs //= 2
+    if slabs > 1:
+      gw = torch.bmm(gy.view(slabs, B // slabs, n_out).transpose(1, 2),
+                     x.reshape(slabs, B // slabs, x.shape[1])).sum(0)
+    else:
+      gw = gy.t() @ x
+    return gx, gw, gy.sum(0)
+
+
+class SkinnyLinear(nn.Linear):
+  """nn.Linear (same parameters, same init, same forward values) whose backward splits the
+  batch reduction of the weight gradient; used for large device batches only."""
+
+  SPLIT_MIN_BATCH = 2048
+
+  def forward(self, x):
+    if x.is_cuda and x.dim() == 2 and x.shape[0] >= self.SPLIT_MIN_BATCH and torch.is_grad_enabled() \
+        and self.bias is not None:
+      return _SplitKLinearFn.apply(x, self.weight, self.bias)
+    return super().forward(x)
+
+
 def _as_sizes(hidden, depth):
   """int -> `depth` hidden layers of that width; tuple/list -> as given."""
   if isinstance(hidden, (tuple, list)):
@@ -24,9 +68,9 @@ def _mlp(n_in, hidden_sizes, n_out, tail=None):
   """Linear/ReLU stack whose Linear layers sit at even Sequential indices (0, 2, 4, ...)."""
   layers, width = [], n_in
   for h in hidden_sizes:
-    layers += [nn.Linear(width, h), nn.ReLU()]
+    layers += [SkinnyLinear(width, h), nn.ReLU()]
     width = h
-  layers.append(nn.Linear(width, n_out))
+  layers.append(SkinnyLinear(width, n_out))
   if tail is not None:
     layers.append(tail)
   return nn.Sequential(*layers)

@@ -26,6 +26,7 @@ struct ColArgs {
   int32_t w_bytes[TRL_MAX_COLS];  // column width in bytes
   int32_t sdt[TRL_MAX_COLS];      // storage dtype
   int32_t odt[TRL_MAX_COLS];      // dtype on the dense side (gather output / push source)
+  int32_t pre_dw[TRL_MAX_COLS + 1];  // gather: prefix sum of the listed columns' dwords
   void *ptr[TRL_MAX_COLS];        // dense per-column arrays
 };
 
@@ -56,6 +57,24 @@ __device__ __forceinline__ Hit find_col(const ColArgs &a, int d) {
   return h;
 }
 
+// k-th dword of the listed columns taken back to back (padding and unlisted columns skipped)
+__device__ __forceinline__ Hit find_packed(const ColArgs &a, int k, int *d) {
+  Hit h{-1, 0, 0, 0, 0, nullptr};
+#pragma unroll
+  for (int i = 0; i < TRL_MAX_COLS; ++i) {
+    if (i < a.ncols && k >= a.pre_dw[i] && k < a.pre_dw[i + 1]) {
+      h.c = i;
+      h.off_dw = a.off_dw[i];
+      h.w_bytes = a.w_bytes[i];
+      h.sdt = a.sdt[i];
+      h.odt = a.odt[i];
+      h.ptr = (char *)a.ptr[i];
+      *d = a.off_dw[i] + (k - a.pre_dw[i]);
+    }
+  }
+  return h;
+}
+
 __device__ __forceinline__ int64_t logical_to_record(int64_t i, int64_t head, int64_t count,
                                                      int64_t capacity) {
   if (i < 0) i += count;           // torch-style negative index
@@ -70,8 +89,8 @@ constexpr int NARROW_ROWS = 64;  // rows per block = one wave-wide index load
 template <bool RANGE>
 __global__ __launch_bounds__(256) void k_gather_narrow(
     const uint32_t *__restrict__ ring, int64_t capacity, int64_t stride_dw, int64_t head,
-    int64_t count, const int64_t *__restrict__ idx, int64_t start, int64_t B, ColArgs a,
-    int region_off_dw, int region_dw, uint32_t magic) {
+    int64_t count, const int64_t *__restrict__ idx, int64_t start, int64_t B, ColArgs a, int nd,
+    uint32_t magic) {
   __shared__ int64_t s_rec[NARROW_ROWS];
   const int64_t row0 = (int64_t)blockIdx.x * NARROW_ROWS;
   const int nrows = (int)((B - row0) < NARROW_ROWS ? (B - row0) : NARROW_ROWS);
@@ -84,12 +103,12 @@ __global__ __launch_bounds__(256) void k_gather_narrow(
     s_rec[threadIdx.x] = p * stride_dw;
   }
   __syncthreads();
-  const int total = nrows * region_dw;
+  const int total = nrows * nd;   // nd = dwords of the listed columns per row
 #pragma unroll 2
   for (int e = threadIdx.x; e < total; e += 256) {
-    const int r = (int)(((uint64_t)(uint32_t)e * magic) >> 32);  // e / region_dw
-    const int d = e - r * region_dw + region_off_dw;
-    const Hit h = find_col(a, d);
+    const int r = (int)(((uint64_t)(uint32_t)e * magic) >> 32);  // e / nd
+    int d = 0;
+    const Hit h = find_packed(a, e - r * nd, &d);
     if (h.c < 0) continue;
     const uint32_t v = ring[s_rec[r] + d];
     const int j = d - h.off_dw;
@@ -295,7 +314,6 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
 
   ColArgs na{};
   WideArgs wa{};
-  int region_lo = INT32_MAX, region_hi = 0;
   for (int c = 0; c < layout->ncols; ++c) {
     TRL_REQUIRE(dst[c] != nullptr, "%s: dst[%d] is null", fn, c);
     const int od = out_dtype[c];
@@ -318,23 +336,21 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
       na.sdt[i] = layout->col_dtype[c];
       na.odt[i] = od;
       na.ptr[i] = dst[c];
-      const int lo = na.off_dw[i], hi = lo + (layout->col_bytes[c] + 3) / 4;
-      region_lo = lo < region_lo ? lo : region_lo;
-      region_hi = hi > region_hi ? hi : region_hi;
+      na.pre_dw[i + 1] = na.pre_dw[i] + (layout->col_bytes[c] + 3) / 4;
     }
   }
   if (na.ncols > 0) {
-    const int region_dw = region_hi - region_lo;
-    TRL_REQUIRE((int64_t)region_dw * NARROW_ROWS < (1 << 22),
-                "%s: narrow region of %d dwords is too wide for the narrow kernel", fn, region_dw);
-    const uint32_t magic = (uint32_t)(((1ull << 32) + region_dw - 1) / region_dw);
+    const int nd = na.pre_dw[na.ncols];
+    TRL_REQUIRE((int64_t)nd * NARROW_ROWS < (1 << 22), "%s: %d narrow dwords per row is too wide for the narrow kernel",
+                fn, nd);
+    const uint32_t magic = (uint32_t)(((1ull << 32) + nd - 1) / nd);
     const unsigned grid = (unsigned)trl_cdiv(B, NARROW_ROWS);
     if (range)
       hipLaunchKernelGGL(k_gather_narrow<true>, dim3(grid), dim3(256), 0, st, (const uint32_t *)ring,
-                         capacity, stride / 4, head, count, idx, start, B, na, region_lo, region_dw, magic);
+                         capacity, stride / 4, head, count, idx, start, B, na, nd, magic);
     else
       hipLaunchKernelGGL(k_gather_narrow<false>, dim3(grid), dim3(256), 0, st, (const uint32_t *)ring,
-                         capacity, stride / 4, head, count, idx, start, B, na, region_lo, region_dw, magic);
+                         capacity, stride / 4, head, count, idx, start, B, na, nd, magic);
     TRL_CHECK_LAUNCH(fn);
   }
   if (wa.ncols > 0) {

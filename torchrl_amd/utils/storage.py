@@ -242,10 +242,10 @@ class TensorTupleDataset(Dataset):
                                                dstp, odt, _lib.stream_ptr(self._device)))
     return outs
 
-  def _gather_index(self, idx):
-    """idx: int64 tensor [B] on the device."""
+  def _gather_index(self, idx, out=None):
+    """idx: int64 tensor [B] on the device; out: (outs, dstp, odt) from _alloc_out to reuse."""
     B = idx.numel()
-    outs, dstp, odt = self._alloc_out(B)
+    outs, dstp, odt = out if out is not None else self._alloc_out(B)
     if B:
       with torch.cuda.device(self._device):
         _lib.check(_lib.lib().trl_gather_rows(self._ring.data_ptr(), self._capacity, self._layout.stride,
