@@ -54,6 +54,7 @@ def parse():
   ap.add_argument('--kernel-iters', type=int, default=50)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
+  ap.add_argument('--no-graph', action='store_true', help='eager learn() instead of HIP-graph replay')
   return ap.parse_args()
 
 
@@ -61,13 +62,23 @@ def setup_dist(args):
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
-  torch.cuda.set_device(local)
+  torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+  local = local % max(1, torch.cuda.device_count())
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    backend = os.environ.get('TRL_BENCH_BACKEND', 'nccl')   # 'gloo' lets a 1-GPU box rehearse N ranks
+    if backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
   if args.gpus != world and rank == 0:
     print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
   return rank, local, world
+
+
+def trace(msg):
+  if os.environ.get('TRL_BENCH_TRACE'):
+    print('[rank %s] %s' % (os.environ.get('RANK', '0'), msg), file=sys.stderr, flush=True)
 
 
 def barrier(world):
@@ -140,7 +151,8 @@ def bench_ppo(args, rank, world, dev):
   warmup = args.warmup if args.warmup is not None else 1
   torch.manual_seed(0)
   ctl = PPOController(obs_size, act_size, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3,
-                      clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden)
+                      clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden, graph=not args.no_graph)
+  trace('controller built')
   obs, action, reward, done, last_next_obs = make_rollout(T, N, obs_size, act_size, dev, 1234 + rank)
   last_done = done[-1]
   n = T * N
@@ -158,14 +170,17 @@ def bench_ppo(args, rank, world, dev):
     logp_em = logp.transpose(0, 1).reshape(n, act_size)
     ret_em, adv_em = returns.reshape(n, 1), adv.reshape(n, 1)
     e1.record()
+    trace('compute_return done')
     for _ in range(args.epochs):
       for s in range(0, n, B):
         e = min(n, s + B)
         ctl.learn(obs_em[s:e], act_em[s:e], None, None, None, ret_em[s:e], logp_em[s:e], adv_em[s:e])
     e2.record()
+    trace('learn epochs issued')
     phase['ev'] = (e0, e1, e2)
 
   dt = timed_steps(step, steps, warmup, world)
+  trace('timed steps done')
   e0, e1, e2 = phase['ev']
   ms_return, ms_learn = e0.elapsed_time(e1), e1.elapsed_time(e2)
   learned = args.epochs * n * steps * world
@@ -188,7 +203,8 @@ def bench_ppo(args, rank, world, dev):
       'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': 'ppo_gae_clip: T=%d, N_envs=%d per GPU, MLP %s, obs 3, act 1' % (T, N, args.hidden),
                  'minibatch': B, 'n_epochs': args.epochs, 'learn_calls_per_step': args.epochs * ((n + B - 1) // B),
-                 'gamma': 0.99, 'lmbda': 0.95, 'clip_ratio': 0.2, 'parallelism': 'dp%d' % world},
+                 'gamma': 0.99, 'lmbda': 0.95, 'clip_ratio': 0.2, 'parallelism': 'dp%d' % world,
+                 'learn_step': 'eager' if args.no_graph else 'hip-graph replay'},
       'roofline': roof,
   }
   res.update(extra)
@@ -288,7 +304,8 @@ def bench_offpolicy(args, rank, world, dev, atari):
               torch.randint(0, 256, (k, 28224), device=dev, dtype=torch.uint8, generator=g),
               (torch.rand(k, 1, device=dev, generator=g) < 0.005).float()]
     fill_ring(ds, cap, cols, 8192)
-    ctl = DQNController(28224, 6, double_dqn=True, gamma=0.99, lr=1e-3, n_update_interval=10, device=dev)
+    ctl = DQNController(28224, 6, double_dqn=True, gamma=0.99, lr=1e-3, n_update_interval=10, device=dev,
+                        graph=not args.no_graph)
     row_bytes, name = 2 * 28224 + 12, 'double_dqn_atari'
     wl = 'double_dqn: %d-row replay of 84x84x4 u8 frames per GPU (%.0f GB), flat-frame QNet 28224-128-128-6' % (
         cap, cap * ds.row_bytes / 1e9)
@@ -301,7 +318,8 @@ def bench_offpolicy(args, rank, world, dev, atari):
               -16 * torch.rand(k, 1, device=dev, generator=g), torch.rand(k, 3, device=dev, generator=g) * 2 - 1,
               (torch.rand(k, 1, device=dev, generator=g) < 0.01).float()]
     fill_ring(ds, cap, cols, 1 << 18)
-    ctl = DDPGController(3, 1, -2.0, 2.0, actor_lr=1e-4, critic_lr=1e-3, gamma=0.99, tau=1e-2, device=dev)
+    ctl = DDPGController(3, 1, -2.0, 2.0, actor_lr=1e-4, critic_lr=1e-3, gamma=0.99, tau=1e-2, device=dev,
+                         graph=not args.no_graph)
     row_bytes, name = 36, 'ddpg_pendulum'
     wl = 'ddpg: %d-row Pendulum-shaped f32 replay per GPU, actor/critic MLP 256x256' % cap
 
@@ -320,7 +338,8 @@ def bench_offpolicy(args, rank, world, dev, atari):
       'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix (bit-exact)',
-                 'parallelism': 'dp%d' % world, 'name': name},
+                 'parallelism': 'dp%d' % world, 'name': name,
+                 'learn_step': 'eager' if args.no_graph else 'hip-graph replay'},
       'roofline': roof,
   }
   return res, dict(cap=cap, B=B, atari=atari)

@@ -174,6 +174,22 @@ int trl_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
                   double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
                   double clip_value /* <= 0: no clamp */, void *stream);
 
+/* The same update with its step-dependent scalars kept ON THE DEVICE, for callers that replay
+ * the learner step from a captured HIP graph (kernel arguments are frozen at capture, the step
+ * count is not).  `state` is a device struct: the launch increments state->step, derives the
+ * bias corrections from it in double precision and applies the update; the host writes the
+ * struct once (and again whenever it changes lr / scale / clip). */
+typedef struct {
+  int64_t step;      /* steps taken so far; incremented by every launch */
+  double lr, beta1, beta2, eps;
+  double grad_scale; /* 1 = none */
+  double clip_value; /* <= 0 = none */
+  float derived[8];  /* scratch of the launch (the per-step scalars) */
+} trl_adam_state;
+
+int trl_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                      trl_adam_state *state, void *stream);
+
 /* target <- tau * source + (1 - tau) * target (ddpg_controller.py:42-57); tau == 1 is
  * the hard sync of dqn_controller.py:85-86. */
 int trl_polyak(float *target, const float *source, int64_t n, double tau, void *stream);

@@ -170,12 +170,13 @@ def test_adam_and_polyak_kernels(n):
 
 
 # ------------------------------------------------------------------ controllers vs golden learn()
-def test_dqn_controller_learn_golden(golden):
+@pytest.mark.parametrize('graph', [False, True])
+def test_dqn_controller_learn_golden(golden, graph):
   g = golden('dqn.npz')
   for ci in range(int(g['n_dqn'])):
     p = 'dqn%d_' % ci
     A = g[p + 'q0.net.4.bias'].shape[0]
-    c = DQNController(4, A, double_dqn=bool(g[p + 'double']), gamma=0.99, lr=1e-3, n_update_interval=2, device=DEV)
+    c = DQNController(4, A, double_dqn=bool(g[p + 'double']), gamma=0.99, lr=1e-3, n_update_interval=2, device=DEV, graph=graph)
     c.q_net.load_state_dict(state_from(g, p + 'q0'))
     c.target_q_net.load_state_dict(state_from(g, p + 't0'))
     for step in range(3):
@@ -187,12 +188,13 @@ def test_dqn_controller_learn_golden(golden):
       _vec_close(sub(c._target.data.cpu().numpy()), g['%sstep%d_t' % (p, step)], atol_frac=2e-6)
 
 
-def test_ddpg_controller_learn_golden(golden):
+@pytest.mark.parametrize('graph', [False, True])
+def test_ddpg_controller_learn_golden(golden, graph):
   g = golden('ddpg.npz')
   for ci in range(int(g['n_ddpg'])):
     p = 'ddpg%d_' % ci
     A = g[p + 'actor0.net.4.bias'].shape[0]
-    c = DDPGController(3, A, -2.0, 2.0, actor_lr=1e-4, critic_lr=1e-3, gamma=0.99, tau=1e-2, device=DEV)
+    c = DDPGController(3, A, -2.0, 2.0, actor_lr=1e-4, critic_lr=1e-3, gamma=0.99, tau=1e-2, device=DEV, graph=graph)
     c.actor.load_state_dict(state_from(g, p + 'actor0'))
     c.critic.load_state_dict(state_from(g, p + 'critic0'))
     c._target_actor.copy_from(c._actor)
@@ -209,12 +211,13 @@ def test_ddpg_controller_learn_golden(golden):
         _vec_close(sub(f.data.cpu().numpy()), g['%sstep%d_%s' % (p, step, nm)], atol_frac=1e-5)
 
 
-def test_a2c_controller_learn_golden(golden):
+@pytest.mark.parametrize('graph', [False, True])
+def test_a2c_controller_learn_golden(golden, graph):
   g = golden('a2c.npz')
   for ci in range(int(g['n_a2c'])):
     p = 'a2c%d_' % ci
     A = g[p + 'net0.actor.2.bias'].shape[0]
-    c = A2CController(4, A, lr=1e-3, alpha=0.5, beta=float(g[p + 'beta']), device=DEV)
+    c = A2CController(4, A, lr=1e-3, alpha=0.5, beta=float(g[p + 'beta']), device=DEV, graph=graph)
     c.ac_net.load_state_dict(state_from(g, p + 'net0'))
     for step in range(2):
       batch = [t(g['%sstep%d_%s' % (p, step, f)], DEV) for f in FIELDS + ('returns',)]
@@ -225,13 +228,14 @@ def test_a2c_controller_learn_golden(golden):
       _vec_close(c._flat.data.cpu().numpy(), g['%sstep%d_net' % (p, step)], atol_frac=1e-5)
 
 
-def test_ppo_controller_learn_golden(golden):
+@pytest.mark.parametrize('graph', [False, True])
+def test_ppo_controller_learn_golden(golden, graph):
   g = golden('ppo.npz')
   for ci in range(int(g['n_ppo'])):
     p = 'ppo%d_' % ci
     A = g[p + 'net0.log_std'].shape[1]
     c = PPOController(3, A, lr=3e-4, alpha=0.5, beta=float(g[p + 'beta']), clip_ratio=0.2,
-                      max_grad_norm=float(g[p + 'max_grad_norm']), device=DEV)
+                      max_grad_norm=float(g[p + 'max_grad_norm']), device=DEV, graph=graph)
     c.ac_net.load_state_dict(state_from(g, p + 'net0'))
     for step in range(2):
       names = FIELDS + ('returns', 'old_log_probs', 'advantages')
@@ -241,6 +245,52 @@ def test_ppo_controller_learn_golden(golden):
         _loss_close(info[k].cpu(), g['%sstep%d_%s' % (p, step, k)])
       _vec_close(c._flat.grad.cpu().numpy(), g['%sstep%d_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
       _vec_close(c._flat.data.cpu().numpy(), g['%sstep%d_net' % (p, step)], atol_frac=1e-5)
+
+
+def test_split_k_linear_matches_nn_linear():
+  """models.SkinnyLinear: same forward values, gradients equal up to fp32 summation order."""
+  torch.manual_seed(0)
+  for (B, i, o) in [(65536, 3, 64), (4096, 64, 64), (8192, 64, 1), (3000, 5, 7)]:
+    ref = torch.nn.Linear(i, o).to(DEV)
+    lin = models.SkinnyLinear(i, o).to(DEV)
+    lin.load_state_dict(ref.state_dict())
+    x = torch.randn(B, i, device=DEV)
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    gy = torch.randn(B, o, device=DEV)
+    y1, y2 = ref(x1), lin(x2)
+    torch.testing.assert_close(y2, y1, rtol=1e-6, atol=1e-6)
+    y1.backward(gy)
+    y2.backward(gy)
+    torch.testing.assert_close(x2.grad, x1.grad, rtol=1e-5, atol=1e-5)
+    scale = float(ref.weight.grad.abs().max())
+    torch.testing.assert_close(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5 * float(ref.bias.grad.abs().max()))
+
+
+def test_graphed_learn_tracks_eager_over_many_steps():
+  """Replayed-graph learn() == eager learn() step for step (incl. Adam's step-dependent bias
+  correction, which lives on the device in graph mode) and handles a second batch shape."""
+  outs = []
+  for graph in (False, True):
+    torch.manual_seed(3)
+    c = PPOController(3, 2, lr=1e-3, beta=1e-3, device=DEV, hidden=(64, 64), graph=graph)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    losses = []
+    for step in range(12):
+      B = 4096 if step % 4 != 3 else 1000
+      obs = torch.randn(B, 3, device=DEV, generator=g)
+      act = torch.randn(B, 2, device=DEV, generator=g)
+      ret = torch.randn(B, 1, device=DEV, generator=g)
+      adv = torch.randn(B, 1, device=DEV, generator=g)
+      with torch.no_grad():
+        _, mean, ls = c.ac_net.heads(obs)
+        old = F.normal_log_prob(mean, ls, act) + 0.1
+      info = c.learn(obs, act, None, None, None, ret, old, adv)
+      losses.append(torch.stack([info[k] for k in ('actor_loss', 'critic_loss', 'entropy_loss')]))
+    assert c.ac_net_optim.step_count == 12
+    outs.append((torch.stack(losses).cpu(), c._flat.data.cpu().clone()))
+  torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-6)
+  torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-6)
 
 
 def test_learn_without_hip_device_raises():

@@ -48,8 +48,12 @@ def build_library(force=False, verbose=True):
   procs = []
   for s in SOURCES:
     obj = os.path.join(LIB_DIR, os.path.splitext(s)[0] + '.o')
-    cmd = [hipcc] + FLAGS + ['-x', 'hip', '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-c',
-                             os.path.join(CSRC, s), '-o', obj]
+    if s.endswith('.cpp'):   # host-only translation unit (no device pass: it uses target_clones)
+      cmd = [shutil.which('g++') or 'g++', '-O3', '-std=c++17', '-fPIC', '-Wall', '-I',
+             os.path.join(ROOT, 'include'), '-c', os.path.join(CSRC, s), '-o', obj]
+    else:
+      cmd = [hipcc] + FLAGS + ['-x', 'hip', '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-c',
+                               os.path.join(CSRC, s), '-o', obj]
     if verbose:
       print(' '.join(cmd), flush=True)
     procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

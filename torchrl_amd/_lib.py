@@ -24,6 +24,13 @@ class RingLayout(C.Structure):
               ('col_dtype', C.c_int32 * TRL_MAX_COLS)]
 
 
+class AdamState(C.Structure):
+  """mirror of trl_adam_state"""
+  _fields_ = [('step', C.c_int64), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+              ('eps', C.c_double), ('grad_scale', C.c_double), ('clip_value', C.c_double),
+              ('derived', C.c_float * 8)]
+
+
 class TrlError(RuntimeError):
   pass
 
@@ -50,6 +57,7 @@ PROTOTYPES = {
     'trl_normal_logp': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'trl_a2c_loss': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp]),
     'trl_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),
+    'trl_adam_step_dev': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'trl_polyak': (C.c_int, [_vp, _vp, _i64, _f64, _vp]),
 }
 

@@ -5,6 +5,7 @@ import torch
 from ... import _lib
 from ...optim import FlatParams, FlatAdam
 from ...parallel import GradSync
+from ...graphs import GraphedStep
 
 
 def resolve_device(device):
@@ -28,4 +29,25 @@ def obs_to_tensor(obs, device):
   return torch.from_numpy(np.asarray(obs)).to(device=device, dtype=torch.float32)
 
 
-__all__ = ['resolve_device', 'need_hip', 'obs_to_tensor', 'FlatParams', 'FlatAdam', 'GradSync']
+class LearnRunner:
+  """Runs a controller's device-side step body eagerly or as a replayed HIP graph.
+
+  body(*tensors) -> tensor of losses; it must do device work only.  With more than one rank the
+  body stops after backward and the caller reduces + steps eagerly (`split` is then True)."""
+
+  def __init__(self, body, optims, extra_state, device, use_graph):
+    self.body, self.optims = body, optims
+    self.graphed = None
+    if use_graph:
+      if device.type != 'cuda':
+        raise _lib.TrlError('graph=True needs a HIP device')
+      state = lambda: [t for o in optims for t in o.state_tensors()] + list(extra_state())
+      self.graphed = GraphedStep(body, state, device)
+
+  def __call__(self, *tensors):
+    if self.graphed is None:
+      return self.body(*tensors)
+    return self.graphed(*tensors).clone()      # the static output is overwritten by the next replay
+
+
+__all__ = ['resolve_device', 'need_hip', 'obs_to_tensor', 'FlatParams', 'FlatAdam', 'GradSync', 'LearnRunner']

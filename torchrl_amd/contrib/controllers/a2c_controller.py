@@ -4,21 +4,22 @@ import torch
 from ...controllers import Controller
 from ... import functional as F
 from ..models import A2CNet
-from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
 
 
 class A2CController(Controller):
   def __init__(self, obs_size, action_size,
                gamma=0.99, lmbda=1.0, lr=1e-3,
                alpha=0.5, beta=1.0, device=None,
-               hidden=256, process_group=None):
+               hidden=256, process_group=None, graph=False):
     self.device = resolve_device(device)
 
     self.ac_net = A2CNet(obs_size, action_size, hidden).to(self.device)
     self._flat = FlatParams(self.ac_net)
-    self.ac_net_optim = FlatAdam(self._flat, lr=lr)
     self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._flat)
+    self.ac_net_optim = FlatAdam(self._flat, lr=lr, grad_scale=self._sync.scale, device_state=graph)
+    self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma
     self.lmbda = lmbda
@@ -50,13 +51,20 @@ class A2CController(Controller):
                            env_major_out=env_major_out)
     return returns, adv, values
 
-  def learn(self, obs, action, reward, next_obs, done, returns):  # pylint: disable=unused-argument
-    need_hip(self.device, 'A2CController.learn')
+  def _learn_body(self, obs, action, returns):
     value, probs = self.ac_net.heads(obs)
     loss, parts = F.a2c_loss(probs, value, action, returns, self.alpha, self.beta)
-
     self.ac_net_optim.zero_grad()
     loss.backward()
-    self.ac_net_optim.step(grad_scale=self._sync.all_reduce(self._flat))
+    if not self._sync.enabled:
+      self.ac_net_optim.step()
+    return parts
 
+  def learn(self, obs, action, reward, next_obs, done, returns):  # pylint: disable=unused-argument
+    need_hip(self.device, 'A2CController.learn')
+    parts = self._run(obs, action, returns)
+    if self._sync.enabled:
+      self._sync.all_reduce(self._flat)
+      self.ac_net_optim.step()
+    self.ac_net_optim.note_step()
     return dict(actor_loss=parts[0], critic_loss=parts[1], entropy_loss=parts[2])

@@ -5,7 +5,7 @@ import torch
 from ...controllers import Controller
 from ... import functional as F
 from ..models import DDPGActorNet, DDPGCriticNet
-from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
 
 
 class OUNoise:
@@ -53,7 +53,7 @@ class DDPGController(Controller):
                action_low, action_high,
                actor_lr=1e-4, critic_lr=1e-3, gamma=0.99,
                tau=1e-2, n_reset_interval=100, device=None,
-               hidden=256, huber_delta=None, process_group=None):
+               hidden=256, huber_delta=None, process_group=None, graph=False):
     self.device = resolve_device(device)
     self.action_low = action_low
     self.action_high = action_high
@@ -63,16 +63,19 @@ class DDPGController(Controller):
     self.target_actor = DDPGActorNet(obs_size, action_size, hidden).to(self.device)
     self._actor, self._target_actor = FlatParams(self.actor), FlatParams(self.target_actor)
     self._target_actor.copy_from(self._actor)
-    self.actor_optim = FlatAdam(self._actor, lr=actor_lr)
 
     self.critic = DDPGCriticNet(obs_size, action_size, hidden).to(self.device)
     self.target_critic = DDPGCriticNet(obs_size, action_size, hidden).to(self.device)
     self._critic, self._target_critic = FlatParams(self.critic), FlatParams(self.target_critic)
     self._target_critic.copy_from(self._critic)
-    self.critic_optim = FlatAdam(self._critic, lr=critic_lr)
 
     self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._actor, self._target_actor, self._critic, self._target_critic)
+    self.actor_optim = FlatAdam(self._actor, lr=actor_lr, grad_scale=self._sync.scale, device_state=graph)
+    self.critic_optim = FlatAdam(self._critic, lr=critic_lr, grad_scale=self._sync.scale, device_state=graph)
+    self._run = LearnRunner(self._learn_body, [self.actor_optim, self.critic_optim],
+                            lambda: [self._target_actor.data, self._target_critic.data], self.device,
+                            graph and not self._sync.enabled)
 
     self.gamma = gamma
     self.tau = tau
@@ -88,11 +91,7 @@ class DDPGController(Controller):
       self.noise.reset()
     return action
 
-  def learn(self, obs, action, reward, next_obs, done):
-    need_hip(self.device, 'DDPGController.learn')
-    self.actor.train()
-    self.critic.train()
-
+  def _learn_body(self, obs, action, reward, next_obs, done):
     actor_loss = -self.critic(obs, self.actor(obs)).mean()
 
     current_q = self.critic(obs, action)
@@ -106,13 +105,23 @@ class DDPGController(Controller):
     # the actor's parameters yields the same actor gradient without the wasted matmuls.
     self.actor_optim.zero_grad()
     torch.autograd.backward(actor_loss, inputs=self._actor.params)
-    self.actor_optim.step(grad_scale=self._sync.all_reduce(self._actor))
+    self._sync.all_reduce(self._actor)
+    self.actor_optim.step()
 
     self.critic_optim.zero_grad()
     critic_loss.backward()
-    self.critic_optim.step(grad_scale=self._sync.all_reduce(self._critic))
+    self._sync.all_reduce(self._critic)
+    self.critic_optim.step()
 
     self._target_actor.polyak_from(self._actor, self.tau)
     self._target_critic.polyak_from(self._critic, self.tau)
+    return torch.stack([actor_loss.detach(), critic_loss.detach()])
 
-    return dict(actor_loss=actor_loss.detach(), critic_loss=critic_loss.detach())
+  def learn(self, obs, action, reward, next_obs, done):
+    need_hip(self.device, 'DDPGController.learn')
+    self.actor.train()
+    self.critic.train()
+    losses = self._run(obs, action, reward, next_obs, done)
+    self.actor_optim.note_step()
+    self.critic_optim.note_step()
+    return dict(actor_loss=losses[0], critic_loss=losses[1])

@@ -12,7 +12,7 @@ from ...controllers import Controller
 from ...utils.schedule import ExpDecaySchedule
 from ... import functional as F
 from ..models import QNet
-from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
 
 
 def epsilon_greedy(action_size: int, choices: np.ndarray, eps: float = 0.1):
@@ -34,7 +34,7 @@ class DQNController(Controller):
                double_dqn=False, gamma=.99, lr=1e-3,
                eps_max=1.0, eps_min=1e-2, n_eps_anneal=1000,
                n_update_interval=5, device=None,
-               huber_delta=None, hidden=128, process_group=None):
+               huber_delta=None, hidden=128, process_group=None, graph=False):
     self.action_size = action_size
     self.device = resolve_device(device)
 
@@ -43,9 +43,10 @@ class DQNController(Controller):
     self._q = FlatParams(self.q_net)
     self._target = FlatParams(self.target_q_net)
     self._target.copy_from(self._q)            # target_q_net.load_state_dict(q_net.state_dict())
-    self.q_net_optim = FlatAdam(self._q, lr=lr)
     self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._q, self._target)
+    self.q_net_optim = FlatAdam(self._q, lr=lr, grad_scale=self._sync.scale, device_state=graph)
+    self._run = LearnRunner(self._learn_body, [self.q_net_optim], lambda: [], self.device, graph)
 
     self.double_dqn = double_dqn
     self.gamma = gamma
@@ -60,23 +61,31 @@ class DQNController(Controller):
     actions = epsilon_greedy(self.action_size, greedy, self.eps.value)
     return [a[0] for a in actions]
 
-  def learn(self, obs, action, reward, next_obs, done):
-    need_hip(self.device, 'DQNController.learn')
-    self.q_net.train()
+  def _learn_body(self, obs, action, reward, next_obs, done):
     q = self.q_net(obs)
     with torch.no_grad():
       q_next_target = self.target_q_net(next_obs)
       q_next_online = self.q_net(next_obs) if self.double_dqn else None
     loss = F.td_loss(q, q_next_target, action, reward, done, self.gamma,
                      q_next_online=q_next_online, huber_delta=self.huber_delta)
-
     self.q_net_optim.zero_grad()
     loss.backward()
-    self.q_net_optim.step(grad_scale=self._sync.all_reduce(self._q))
+    if not self._sync.enabled:
+      self.q_net_optim.step()
+    return loss.detach()
+
+  def learn(self, obs, action, reward, next_obs, done):
+    need_hip(self.device, 'DQNController.learn')
+    self.q_net.train()
+    loss = self._run(obs, action, reward, next_obs, done)
+    if self._sync.enabled:
+      self._sync.all_reduce(self._q)
+      self.q_net_optim.step()
+    self.q_net_optim.note_step()
 
     self._steps += 1
     if self._steps % self.n_update_interval == 0:
       self._target.copy_from(self._q)
 
     # 0-d tensor left on the device: the reference's `.cpu()` here is a host sync per step
-    return dict(td_loss=loss.detach())
+    return dict(td_loss=loss)

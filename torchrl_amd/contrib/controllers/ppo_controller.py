@@ -5,7 +5,7 @@ import torch
 from ...controllers import Controller
 from ... import functional as F
 from ..models import ActorCriticNet
-from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync
+from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
 
 
 class PPOController(Controller):
@@ -13,14 +13,18 @@ class PPOController(Controller):
                gamma=0.99, lmbda=1.0, lr=1e-3,
                alpha=0.5, beta=1.0, clip_ratio=0.2,
                max_grad_norm=1.0, device=None,
-               hidden=256, process_group=None):
+               hidden=256, process_group=None, graph=False):
     self.device = resolve_device(device)
 
     self.ac_net = ActorCriticNet(obs_size, action_size, hidden).to(self.device)
     self._flat = FlatParams(self.ac_net)
-    self.ac_net_optim = FlatAdam(self._flat, lr=lr)
     self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._flat)
+    # clip_grad_value_ (an elementwise clamp, ppo_controller.py:72-73) and the 1/world_size of
+    # the data-parallel mean are folded into the Adam launch, i.e. applied after the reduction
+    self.ac_net_optim = FlatAdam(self._flat, lr=lr, grad_scale=self._sync.scale, clip_value=max_grad_norm,
+                                 device_state=graph)
+    self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma
     self.lmbda = lmbda
@@ -62,17 +66,23 @@ class PPOController(Controller):
       log_probs = F.normal_log_prob(mean, log_std, action.reshape(T * N, -1)).view(T, N, -1)
     return returns, adv, log_probs, values
 
-  def learn(self, obs, action, reward, next_obs, done,  # pylint: disable=unused-argument
-            returns, old_log_probs, advantages):
-    need_hip(self.device, 'PPOController.learn')
+  def _learn_body(self, obs, action, returns, old_log_probs, advantages):
+    """Device work of one learn(): forward, fused loss, backward and (single rank) the update."""
     value, mean, log_std = self.ac_net.heads(obs)
     loss, parts = F.ppo_loss(mean, log_std, value, action, old_log_probs, advantages, returns,
                              self.clip_ratio, self.alpha, self.beta)
-
     self.ac_net_optim.zero_grad()
     loss.backward()
-    # clip_grad_value_ (an elementwise clamp, ppo_controller.py:72-73) is folded into the
-    # Adam launch and applied after the data-parallel reduction
-    self.ac_net_optim.step(grad_scale=self._sync.all_reduce(self._flat), clip_value=self.max_grad_norm)
+    if not self._sync.enabled:
+      self.ac_net_optim.step()
+    return parts
 
+  def learn(self, obs, action, reward, next_obs, done,  # pylint: disable=unused-argument
+            returns, old_log_probs, advantages):
+    need_hip(self.device, 'PPOController.learn')
+    parts = self._run(obs, action, returns, old_log_probs, advantages)
+    if self._sync.enabled:
+      self._sync.all_reduce(self._flat)
+      self.ac_net_optim.step()
+    self.ac_net_optim.note_step()
     return dict(actor_loss=parts[0], critic_loss=parts[1], entropy_loss=parts[2])

@@ -381,6 +381,43 @@ __global__ __launch_bounds__(NT) void k_adam(float *__restrict__ p, float *__res
   }
 }
 
+// graph-replay form: scalars derived on the device from the device-resident step counter
+__global__ void k_adam_prep(trl_adam_state *st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t step = st->step + 1;
+    st->step = step;
+    AdamScalars s;
+    s.w1 = (float)(1.0 - st->beta1);
+    s.beta2 = (float)st->beta2;
+    s.c2 = (float)(1.0 - st->beta2);
+    s.bc2_sqrt = (float)sqrt(1.0 - pow(st->beta2, (double)step));
+    s.eps = (float)st->eps;
+    s.neg_step = (float)(-(st->lr / (1.0 - pow(st->beta1, (double)step))));
+    s.scale = (float)st->grad_scale;
+    s.clip = (float)st->clip_value;
+    *(AdamScalars *)st->derived = s;
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_adam_dev(float *__restrict__ p, float *__restrict__ g,
+                                                 float *__restrict__ m, float *__restrict__ v, int64_t n,
+                                                 const trl_adam_state *__restrict__ st) {
+  const AdamScalars s = *(const AdamScalars *)st->derived;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    float gi = g[i];
+    if (s.scale != 1.0f) gi = __fmul_rn(gi, s.scale);
+    if (s.clip > 0.f) gi = fminf(fmaxf(gi, -s.clip), s.clip);
+    if (s.scale != 1.0f || s.clip > 0.f) g[i] = gi;
+    float mi = m[i], vi = v[i];
+    mi = __fadd_rn(mi, __fmul_rn(s.w1, __fsub_rn(gi, mi)));
+    vi = __fadd_rn(__fmul_rn(vi, s.beta2), __fmul_rn(__fmul_rn(s.c2, gi), gi));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), s.bc2_sqrt), s.eps);
+    p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(s.neg_step, mi), denom));
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 __global__ __launch_bounds__(NT) void k_polyak(float *__restrict__ t, const float *__restrict__ s, int64_t n,
                                                float tau, float omt) {
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
@@ -517,6 +554,24 @@ extern "C" int trl_adam_step(float *param, float *grad, float *exp_avg, float *e
   s.clip = (float)clip_value;
   hipLaunchKernelGGL(k_adam, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, n, s);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+static_assert(sizeof(AdamScalars) == 32, "AdamScalars must fill trl_adam_state::derived");
+
+extern "C" int trl_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                 trl_adam_state *state, void *stream) {
+  const char *fn = "trl_adam_step_dev";
+  TRL_REQUIRE(param && grad && exp_avg && exp_avg_sq && state, "%s: null pointer", fn);
+  TRL_REQUIRE(n >= 0, "%s: n < 0", fn);
+  TRL_REQUIRE((uintptr_t)state % 8 == 0, "%s: state must be 8-byte aligned", fn);
+  if (n == 0) return TRL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(64), 0, st, state);
+  TRL_CHECK_LAUNCH(fn);
+  hipLaunchKernelGGL(k_adam_dev, dim3(ew_grid(n)), dim3(NT), 0, st, param, grad, exp_avg, exp_avg_sq, n,
+                     (const trl_adam_state *)state);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
 }

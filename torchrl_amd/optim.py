@@ -62,24 +62,70 @@ class FlatParams:
 
 class FlatAdam:
   """torch.optim.Adam(lr=lr) semantics (betas (0.9, 0.999), eps 1e-8, no weight decay, no
-  amsgrad) over a FlatParams, as one kernel launch per step."""
+  amsgrad) over a FlatParams, as one kernel launch per step.
 
-  def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+  grad_scale / clip_value are applied to the gradient inside the same launch (1/world_size
+  after the all-reduce; torch.nn.utils.clip_grad_value_).  With device_state=True the step
+  count and hyper-parameters live in a device struct (trl_adam_state) and the launch derives
+  the bias corrections there, which is what a captured HIP graph needs (kernel arguments are
+  frozen at capture, the step count is not)."""
+
+  def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, clip_value=0.0,
+               device_state=False):
     self.flat = flat
     self.lr, self.betas, self.eps = lr, betas, eps
+    self.grad_scale, self.clip_value = grad_scale, clip_value
     self.exp_avg = torch.zeros_like(flat.data)
     self.exp_avg_sq = torch.zeros_like(flat.data)
     self.step_count = 0
+    self.device_state = device_state
+    self._state_dev = None
 
   def zero_grad(self):
     self.flat.zero_grad()
 
-  def step(self, grad_scale=1.0, clip_value=0.0):
+  def _push_state(self):
+    """(Re)write the device struct from the host-side values."""
+    st = _lib.AdamState(step=self.step_count, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                        eps=self.eps, grad_scale=self.grad_scale, clip_value=self.clip_value)
+    host = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
+    if self._state_dev is None:
+      self._state_dev = torch.empty(host.numel() + 8, dtype=torch.uint8, device=self.flat.device)
+      off = (-self._state_dev.data_ptr()) % 8
+      self._state_dev = self._state_dev[off:off + host.numel()]
+    self._state_dev.copy_(host)
+
+  def state_tensors(self):
+    """Device tensors a step mutates (for GraphedStep's warm-up restore)."""
+    out = [self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq]
+    if self.device_state:
+      if self._state_dev is None:
+        self._push_state()
+      out.append(self._state_dev)
+    return out
+
+  def step(self):
+    """Device work only (safe inside a captured graph); see note_step for the host mirror."""
     if not self.flat.data.is_cuda:
       raise _lib.TrlError('FlatAdam.step needs a HIP device (no CPU update path)')
-    self.step_count += 1
-    F.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
-                 self.lr, self.betas, self.eps, grad_scale, clip_value)
+    if self.device_state:
+      if self._state_dev is None:
+        self._push_state()
+      with torch.cuda.device(self.flat.device):
+        _lib.check(_lib.lib().trl_adam_step_dev(self.flat.data.data_ptr(), self.flat.grad.data_ptr(),
+                                                self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                                self.flat.numel, self._state_dev.data_ptr(),
+                                                _lib.stream_ptr(self.flat.device)))
+    else:
+      self.step_count += 1
+      F.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
+                   self.lr, self.betas, self.eps, self.grad_scale, self.clip_value)
+
+  def note_step(self):
+    """Host mirror of the device step counter: call once per optimizer step when
+    device_state=True (the step itself may have been a graph replay)."""
+    if self.device_state:
+      self.step_count += 1
 
   def state_dict(self):
     return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
@@ -90,3 +136,5 @@ class FlatAdam:
     self.exp_avg.copy_(sd['exp_avg'])
     self.exp_avg_sq.copy_(sd['exp_avg_sq'])
     self.lr, self.betas, self.eps = sd['lr'], tuple(sd['betas']), sd['eps']
+    if self.device_state:
+      self._push_state()

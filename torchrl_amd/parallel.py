@@ -25,6 +25,13 @@ class GradSync:
         dist.get_world_size(process_group) > 1
     self.world_size = dist.get_world_size(process_group) if self.enabled else 1
     self.scale = 1.0 / self.world_size
+    # Drain the compute stream before the collective.  With gloo (device tensors staged through
+    # the host) an all-reduce issued behind replayed HIP graphs was seen to stall without it;
+    # RCCL is stream-ordered and should not need it, but that pairing cannot be exercised on the
+    # one-GPU development box, so the drain stays on unless TRL_ASYNC_ALLREDUCE=1.  It costs one
+    # host wait per optimizer step; the learner step is GPU-bound.
+    import os
+    self._host_staged = self.enabled and os.environ.get('TRL_ASYNC_ALLREDUCE', '0') != '1'
 
   def broadcast_params(self, *flats, src=0):
     """Make every rank start from rank `src`'s weights."""
@@ -35,6 +42,8 @@ class GradSync:
   def all_reduce(self, *flats):
     """Sum the gradients in place; returns the scale for the update (1 / world_size)."""
     if self.enabled:
+      if self._host_staged:
+        torch.cuda.current_stream(flats[0].device).synchronize()
       for f in flats:
         dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self.group)
     return self.scale
