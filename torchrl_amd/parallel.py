@@ -42,7 +42,7 @@ class GradSync:
   def all_reduce(self, *flats):
     """Sum the gradients in place; returns the scale for the update (1 / world_size)."""
     if self.enabled:
-      if self._host_staged:
+      if self._host_staged and flats[0].grad.is_cuda:
         torch.cuda.current_stream(flats[0].device).synchronize()
       for f in flats:
         dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self.group)
