@@ -183,7 +183,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
                                          0, 0);
       }
     };
-    static_assert(PF >= 1 && PF <= 4, "prefetch depth");
+    static_assert(PF >= 1 && PF <= 5, "prefetch depth");
 #pragma unroll
     for (int j = 0; j < PF; ++j)
       if (!(dbg & 8)) issue(j);
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
     if (PF == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     if (PF == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     if (PF == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    if (PF == 5) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < nstages; ++s) {
       if (!(dbg & 8)) issue(s + PF);
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
       if (PF == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       if (PF == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       if (PF == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      if (PF == 5) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain before the LDS is released
@@ -255,8 +257,9 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
                 ad[c] = __fsub_rn(rt[c], v);
               }
               const int64_t g = (int64_t)(lo + tl) * N + envq;
-              *(float4 *)(returns + g) = make_float4(rt[0], rt[1], rt[2], rt[3]);
-              if (adv) *(float4 *)(adv + g) = make_float4(ad[0], ad[1], ad[2], ad[3]);
+              const f32x4 r4 = {rt[0], rt[1], rt[2], rt[3]}, a4 = {ad[0], ad[1], ad[2], ad[3]};
+              *(f32x4 *)(returns + g) = r4;
+              if (adv) *(f32x4 *)(adv + g) = a4;
             }
           }
         } else {
@@ -374,11 +377,11 @@ int launch_pipe(const float *reward, const float *value, const float *bootstrap,
 int dispatch_pipe(int E, int PF, const float *reward, const float *value, const float *bootstrap, int T, int N,
                   float gamma, float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
   if (E == 0) E = N > 256 * 32 ? 64 : (N > 256 * 16 ? 32 : 16);
-  if (PF == 0) PF = 3;
+  if (PF == 0) PF = 2;   // deeper prefetch measured no faster, cold or cache-resident (tools/gae_sweep.py)
 #define TRL_PIPE_CASE(e, pf)  \
   if (E == e && PF == pf)     \
     return launch_pipe<e, pf>(reward, value, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
-  TRL_PIPE_CASE(16, 2) TRL_PIPE_CASE(16, 3) TRL_PIPE_CASE(16, 4)
+  TRL_PIPE_CASE(16, 2) TRL_PIPE_CASE(16, 3) TRL_PIPE_CASE(16, 4) 
   TRL_PIPE_CASE(32, 2) TRL_PIPE_CASE(32, 3) TRL_PIPE_CASE(32, 4)
   TRL_PIPE_CASE(64, 2) TRL_PIPE_CASE(64, 3) TRL_PIPE_CASE(64, 4)
 #undef TRL_PIPE_CASE
