@@ -246,7 +246,7 @@ def cpu_baseline_ppo(info):
   from torchrl_amd.contrib.models import ActorCriticNet
   torch.set_num_threads(1)
   T, hidden, B, epochs = info['T'], info['hidden'], info['B'], info['epochs']
-  n_envs = 32
+  n_envs = 384     # ~10 s of host work
   torch.manual_seed(0)
   net = ActorCriticNet(3, 1, hidden)
   opt = torch.optim.Adam(net.parameters(), lr=3e-4)
