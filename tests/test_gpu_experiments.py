@@ -1,0 +1,90 @@
+"""End-to-end experiments on the device (BASELINE config 1 plumbing): the assertions of the
+reference's examples/test_examples.py on the built-in envs, plus rollout-buffer parity with
+the reference-shaped per-env path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
+
+from torchrl_amd.contrib.controllers import PPOController  # noqa: E402
+from torchrl_amd.utils.rollout import RolloutBuffer, env_major, iter_minibatches  # noqa: E402
+from torchrl_amd.utils.storage import Transition, TransitionTupleDataset  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_dqn_exp(graph):
+  from dqn import DQNExperiment
+  exp = DQNExperiment(env_id='CartPole-v1', n_frames=600, buffer_size=500, n_train_interval=10, seed=0, graph=graph)
+  exp.run()
+  assert len(exp.buffer) == min(500, 600) and exp._cur_frames == 600
+  assert exp.buffer.device.type == 'cuda'
+  loss, step = exp.logger.last['train/td_loss']
+  assert torch.isfinite(loss).item() and step == 600
+  assert exp.controller._steps == exp.controller.q_net_optim.step_count > 0
+
+
+def test_ddpg_exp():
+  from ddpg import DDPGExperiment
+  exp = DDPGExperiment(env_id='Pendulum-v0', n_frames=800, buffer_size=500, n_train_interval=20, seed=0)
+  exp.run()
+  assert len(exp.buffer) == 500 and exp._cur_frames == 800
+  assert all(torch.isfinite(exp.logger.last['train/' + k][0]).item() for k in ('actor_loss', 'critic_loss'))
+
+
+def test_a2c_exp():
+  from a2c import A2CExperiment
+  exp = A2CExperiment(env_id='CartPole-v1', n_envs=4, n_frames=600, seed=0)
+  exp.run()
+  assert exp._cur_frames == 600 and len(exp.rollout) == 0
+  assert torch.isfinite(exp.logger.last['train/critic_loss'][0]).item()
+
+
+def test_ppo_exp():
+  from ppo import PPOExperiment
+  exp = PPOExperiment(env_id='Pendulum-v0', n_envs=4, n_frames=800, rollout_steps=20, lmbda=0.95, seed=0)
+  exp.run()
+  assert exp._cur_frames == 800
+  assert torch.isfinite(exp.logger.last['train/actor_loss'][0]).item()
+
+
+def test_rollout_buffer_matches_per_env_reference_path():
+  """[T, N] staging + one batched compute_return == the reference's per-env buffers +
+  per-env compute_return + torch.cat, in the reference's env-major minibatch order."""
+  dev = 'cuda:0'
+  T, N = 23, 5
+  rs = np.random.RandomState(0)
+  torch.manual_seed(0)
+  ctl = PPOController(3, 2, gamma=0.99, lmbda=0.95, device=dev)
+  roll = RolloutBuffer(N, device=dev, initial_steps=4)
+  per_env = [TransitionTupleDataset(device=dev) for _ in range(N)]
+  for t in range(T):
+    tl = [Transition(rs.randn(3).astype(np.float32), rs.randn(2).astype(np.float32), float(rs.randn()),
+                     rs.randn(3).astype(np.float32), bool(t == T - 1 and e % 2)) for e in range(N)]
+    roll.extend(tl)
+    for buf, tr in zip(per_env, tl):
+      buf.extend([tr])
+  assert len(roll) == T
+  obs, action, reward, done, last_next = roll.tensors()
+  ret, adv, lp, val = ctl.compute_return_batched(obs, action, reward, last_next, done[-1], env_major_out=True)
+  cols = [env_major(obs), env_major(action), ret.reshape(-1, 1), env_major(lp), adv.reshape(-1, 1)]
+  ref = [[] for _ in range(5)]
+  for buf in per_env:                                   # examples/ppo.py:49-59
+    batch = buf[:]
+    r, l, v = ctl.compute_return(*batch)
+    for dst, x in zip(ref, (batch[0], batch[1], r, l, r - v)):
+      dst.append(x)
+  ref = [torch.cat(c, 0) for c in ref]
+  for got, exp in zip(cols, ref):
+    assert got.shape == exp.shape
+    torch.testing.assert_close(got, exp, rtol=1e-5, atol=1e-5)
+  assert torch.equal(cols[0], ref[0]) and torch.equal(cols[1], ref[1])      # data columns: exact
+  sizes = [b[0].shape[0] for b in iter_minibatches(cols, 32)]
+  assert sizes == [32, 32, 32, 19]
+  roll.truncate()
+  assert len(roll) == 0

@@ -1,0 +1,97 @@
+"""Device-resident on-policy rollout staging ([T, N, .] tensors).
+
+The reference keeps one TransitionTupleDataset per env, appends one transition per env per step
+(`torch.cat` of the whole column each time), and at train time walks the envs in Python:
+`buffer[:]`, `compute_return`, `torch.cat` over envs (examples/ppo.py:28-35, 43-68; a2c.py the
+same).  Here one env step over all N envs is ONE row of preallocated `[T, N, .]` device
+tensors (a single small H2D copy per column), the return/advantage pass is one batched call,
+and minibatches come out in the reference's order: env-major, sequential, last partial batch
+kept (`DataLoader(ds, batch_size)` at examples/ppo.py:68).
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class RolloutBuffer:
+  def __init__(self, n_envs, device=None, initial_steps=32):
+    self.n_envs = n_envs
+    self._device = torch.device(device) if device is not None else None
+    self._cap = initial_steps
+    self._t = 0
+    self._cols = None          # obs, action, reward, done  [cap, N, .]
+    self._last_next_obs = None
+    self._pin = None
+
+  def __len__(self):
+    return self._t
+
+  def _bind(self):
+    if self._device is None:
+      if not torch.cuda.is_available():
+        raise _lib.TrlError('RolloutBuffer needs a HIP device (no CPU fallback)')
+      self._device = torch.device('cuda', torch.cuda.current_device())
+    if self._device.type != 'cuda':
+      raise _lib.TrlError('RolloutBuffer lives on a HIP device, not %s' % self._device)
+
+  def _alloc(self, widths, cap):
+    return [torch.empty((cap, self.n_envs, w), dtype=torch.float32, device=self._device) for w in widths]
+
+  def extend(self, transition_list):
+    """One Transition per env (env order), i.e. one time step; fields become float32 like
+    TransitionTupleDataset.extend (storage.py:65-67)."""
+    if len(transition_list) != self.n_envs:
+      raise ValueError('expected %d transitions (one per env), got %d' % (self.n_envs, len(transition_list)))
+    self._bind()
+    fields = [np.asarray(f, dtype=np.float32).reshape(self.n_envs, -1) for f in zip(*transition_list)]
+    obs, action, reward, next_obs, done = fields
+    row = np.concatenate([obs, action, reward, done, next_obs], axis=1)
+    if self._cols is None:
+      self._widths = [obs.shape[1], action.shape[1], 1, 1]
+      self._cols = self._alloc(self._widths, self._cap)
+      self._last_next_obs = torch.empty((self.n_envs, obs.shape[1]), dtype=torch.float32, device=self._device)
+      self._pin = [torch.empty(row.shape, dtype=torch.float32).pin_memory() for _ in range(8)]
+      self._pin_ev = [None] * 8
+      self._stage = torch.empty(row.shape, dtype=torch.float32, device=self._device)
+    if self._t == self._cap:
+      new = self._alloc(self._widths, 2 * self._cap)
+      for n, o in zip(new, self._cols):
+        n[:self._cap].copy_(o)
+      self._cols, self._cap = new, 2 * self._cap
+    slot = self._t % len(self._pin)
+    if self._pin_ev[slot] is not None:
+      self._pin_ev[slot].synchronize()
+    self._pin[slot].copy_(torch.from_numpy(row))
+    self._stage.copy_(self._pin[slot], non_blocking=True)       # one H2D per env step
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(self._device))
+    self._pin_ev[slot] = ev
+    off = 0
+    for col, w in zip(self._cols, self._widths):
+      col[self._t].copy_(self._stage[:, off:off + w])
+      off += w
+    self._last_next_obs.copy_(self._stage[:, off:])
+    self._t += 1
+
+  def truncate(self):
+    self._t = 0
+
+  def tensors(self):
+    """(obs [T,N,O], action [T,N,A], reward [T,N], done [T,N], last_next_obs [N,O])."""
+    T = self._t
+    obs, action, reward, done = (c[:T] for c in self._cols)
+    return obs, action, reward[..., 0], done[..., 0], self._last_next_obs
+
+
+def env_major(x):
+  """[T, N, ...] -> [N*T, ...] in the reference's concatenation order (env 0's T rows first)."""
+  T, N = x.shape[:2]
+  return x.transpose(0, 1).reshape((N * T,) + tuple(x.shape[2:]))
+
+
+def iter_minibatches(columns, batch_size):
+  """Sequential minibatches over equally long columns, last partial batch kept."""
+  n = columns[0].shape[0]
+  for s in range(0, n, batch_size):
+    yield [c[s:s + batch_size] for c in columns]
