@@ -213,7 +213,16 @@ def bench_ppo(args, rank, world, dev):
     rot['i'] += 1
     F.gae(s[0], s[1], s[2], 0.99, 0.95, out=s[3])
 
-  us = kernel_time_us(launch_cold, max(args.kernel_iters, 2 * nsets) // nsets * nsets)
+  iters_cold = max(args.kernel_iters, 2 * nsets) // nsets * nsets
+  us = kernel_time_us(launch_cold, iters_cold)
+
+  def copy_cold():      # a plain device copy moving the same bytes over the same rotating sets
+    s = sets[rot['i'] % nsets]
+    rot['i'] += 1
+    s[3][0].copy_(s[0])
+    s[3][1].copy_(s[1])
+
+  us_copy = kernel_time_us(copy_cold, iters_cold)
   s0 = sets[0]
   us_warm = kernel_time_us(lambda: F.gae(s0[0], s0[1], s0[2], 0.99, 0.95, out=s0[3]), args.kernel_iters)
   del sets
@@ -221,6 +230,9 @@ def bench_ppo(args, rank, world, dev):
                   'HBM (%d rotating buffer sets); cache-resident inputs: %.2f us = %.0f GB/s'
                   % (n, nsets, us_warm, algo / us_warm / 1e3),
                   traffic_key='k_gae_pipe<16,3> T=2048 N=4096' if (T, N) == (2048, 4096) else None)
+  roof['copy_ceiling'] = {'GB/s': round(algo / us_copy / 1e3, 1), 'us': round(us_copy, 2),
+                          'note': 'torch device copy of the same bytes over the same cold buffer sets, same process'}
+  roof['frac_of_copy_ceiling'] = round(us_copy / us, 4)
   extra = {'gae_steps_per_sec_kernel': round(n / (us * 1e-6), 1),
            'gae_steps_per_sec_compute_return': round(n / (ms_return * 1e-3), 1),
            'ms_compute_return': round(ms_return, 3), 'ms_learn_epochs': round(ms_learn, 3)}

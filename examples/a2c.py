@@ -10,9 +10,12 @@ from torchrl_amd.utils.rollout import RolloutBuffer, env_major  # noqa: E402
 
 
 class A2CExperiment(BaseExperiment):
-  def __init__(self, gamma=0.99, rollout_steps=5, alpha=0.5, lr=3e-4, beta=1e-3, lmbda=1.0, graph=False,
+  def __init__(self, gamma=0.99, rollout_steps=5, alpha=0.5, lr=3e-4, beta=1e-3, lmbda=1.0, graph=False, mask_dones=False,
                **kwargs):
     self._controller_args = dict(lr=lr, gamma=gamma, lmbda=lmbda, alpha=alpha, beta=beta, graph=graph)
+    # mask_dones=True applies (1 - done) inside the rollout (standard GAE); the reference only looks at
+    # the last step's done (a2c_controller.py:32), which is the default here too
+    self.mask_dones = mask_dones
     kwargs['n_train_interval'] = kwargs.get('n_envs', 1) * rollout_steps
     super().__init__(**kwargs)
     self.rollout = RolloutBuffer(self.envs.n_procs, device=self.device)
@@ -26,8 +29,8 @@ class A2CExperiment(BaseExperiment):
 
   def train(self):
     obs, action, reward, done, last_next_obs = self.rollout.tensors()
-    returns, _, _ = self.controller.compute_return_batched(obs, reward, last_next_obs, done[-1],
-                                                           env_major_out=True)
+    returns, _, _ = self.controller.compute_return_batched(obs, reward, last_next_obs, done[-1], done=done,
+                                                           masked=self.mask_dones, env_major_out=True)
     self.rollout.truncate()
     return self.controller.learn(env_major(obs), env_major(action), None, None, None, returns.reshape(-1, 1))
 

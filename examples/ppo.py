@@ -11,9 +11,12 @@ from torchrl_amd.utils.rollout import RolloutBuffer, env_major, iter_minibatches
 
 class PPOExperiment(BaseExperiment):
   def __init__(self, gamma=0.99, rollout_steps=10, alpha=0.5, lr=3e-4, beta=1e-3, lmbda=1.0, clip_ratio=0.2,
-               max_grad_norm=1.0, batch_size=32, n_epochs=4, graph=False, **kwargs):
+               max_grad_norm=1.0, batch_size=32, n_epochs=4, graph=False, mask_dones=False, **kwargs):
     self._controller_args = dict(lr=lr, gamma=gamma, lmbda=lmbda, alpha=alpha, beta=beta, clip_ratio=clip_ratio,
                                  max_grad_norm=max_grad_norm, graph=graph)
+    # mask_dones=True applies (1 - done) inside the rollout (standard GAE); the reference only looks at
+    # the last step's done (a2c_controller.py:32), which is the default here too
+    self.mask_dones = mask_dones
     kwargs['n_train_interval'] = kwargs.get('n_envs', 1) * rollout_steps
     super().__init__(**kwargs)
     self.rollout = RolloutBuffer(self.envs.n_procs, device=self.device)
@@ -31,7 +34,7 @@ class PPOExperiment(BaseExperiment):
     obs, action, reward, done, last_next_obs = self.rollout.tensors()
     # all envs at once; returns/advantages come back env-major like the reference's torch.cat
     returns, adv, log_probs, _ = self.controller.compute_return_batched(
-        obs, action, reward, last_next_obs, done[-1], env_major_out=True)
+        obs, action, reward, last_next_obs, done[-1], done=done, masked=self.mask_dones, env_major_out=True)
     cols = [env_major(obs), env_major(action), returns.reshape(-1, 1), env_major(log_probs), adv.reshape(-1, 1)]
     self.rollout.truncate()
     train_info = dict()
