@@ -194,6 +194,21 @@ int trl_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_
  * the hard sync of dqn_controller.py:85-86. */
 int trl_polyak(float *target, const float *source, int64_t n, double tau, void *stream);
 
+/* ------------------------------------------------------------------ MLP layers (a-2)
+ * One Linear (+ ReLU) layer of the small policy / value networks (torchrl/contrib/models.py:
+ * QNet :14-20, DDPGActorNet :37-44, DDPGCriticNet :66-72, A2CNet :92-103, ActorCriticNet
+ * :120-130) on f32 MFMA, for the large-batch learner step where the BLAS picks are poor.
+ *   fwd:  y[B, N] = act(x[B, K] @ w[N, K]^T + b[N]);   act: 0 = none, 1 = ReLU.  N <= 256.
+ *   bwd:  g = dy (* (y > 0) for ReLU);  dx[B, K] = g @ w (dx may be NULL);
+ *         dw[N, K] = g^T @ x;  db[N] = column sums of g   (both OVERWRITTEN, not accumulated).
+ * `ws` is a caller-owned device scratch of trl_linear_bwd_workspace_bytes(B, K, N) bytes; the
+ * weight-gradient partials are summed in a fixed order (reproducible, no float atomics). */
+int trl_linear_fwd(const float *x, const float *w, const float *b, int64_t B, int32_t K, int32_t N,
+                   int32_t act, float *y, void *stream);
+int64_t trl_linear_bwd_workspace_bytes(int64_t B, int32_t K, int32_t N);
+int trl_linear_bwd(const float *dy, const float *y, const float *x, const float *w, int64_t B, int32_t K,
+                   int32_t N, int32_t act, float *dx, float *dw, float *db, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,9 @@ PROTOTYPES = {
     'trl_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),
     'trl_adam_step_dev': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'trl_polyak': (C.c_int, [_vp, _vp, _i64, _f64, _vp]),
+    'trl_linear_fwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'trl_linear_bwd_workspace_bytes': (_i64, [_i64, _i32, _i32]),
+    'trl_linear_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -275,3 +275,56 @@ def polyak_(target, source, tau):
   with torch.cuda.device(target.device):
     _lib.check(_lib.lib().trl_polyak(target.data_ptr(), source.data_ptr(), target.numel(), float(tau),
                                      _lib.stream_ptr(target.device)))
+
+
+# ------------------------------------------------------------------------------ MLP layers
+_lin_ws = {}
+
+
+def _linear_ws(device, nbytes):
+  """Per-device scratch for the weight-gradient partials, grown on demand."""
+  key = device.index if device.index is not None else torch.cuda.current_device()
+  ws = _lin_ws.get(key)
+  if ws is None or ws.numel() < nbytes:
+    ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    _lin_ws[key] = ws
+  return ws
+
+
+class _LinearAct(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, weight, bias, act):
+    x = _f32c(x, 'x')
+    w = _f32c(weight, 'weight')
+    b = _f32c(bias, 'bias')
+    B, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().trl_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), B, K, N, act, y.data_ptr(),
+                                           _lib.stream_ptr(x.device)))
+    ctx.act = act
+    ctx.save_for_backward(x, w, y)
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    x, w, y = ctx.saved_tensors
+    gy = gy.contiguous()
+    B, K = x.shape
+    N = w.shape[0]
+    dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+    dw = torch.empty_like(w)
+    db = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = _linear_ws(x.device, _lib.lib().trl_linear_bwd_workspace_bytes(B, K, N))
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().trl_linear_bwd(gy.data_ptr(), y.data_ptr(), x.data_ptr(), w.data_ptr(), B, K, N,
+                                           ctx.act, _lib.ptr(dx), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                           _lib.stream_ptr(x.device)))
+    return dx, dw, db, None
+
+
+def linear_act(x, weight, bias, relu=False):
+  """act(x @ weight^T + bias) for 2-D float32 device tensors, fan-out <= 256: one HIP launch
+  forward, one (+ a small reduce) backward (csrc/trl_mlp.hip)."""
+  return _LinearAct.apply(x, weight, bias, 1 if relu else 0)
