@@ -112,9 +112,17 @@ def test_random_pushes_vs_oracle(obs_shape, u8, size):
   rs = np.random.RandomState(hash((obs_shape, size)) & 0xffff)
   ds = TransitionTupleDataset(size=size, device=DEV, obs_dtype=torch.uint8 if u8 else None)
   ref = replay_oracle.FifoColumns(size=size)
-  for k in [1, 3, size // 2, size - 1, 2, size, 5, size + 7, 1]:
+  for pi, k in enumerate([1, 3, size // 2, size - 1, 2, size, 5, size + 7, 1]):
     tl = _random_transitions(rs, max(k, 1), obs_shape, u8)
-    ds.extend(tl)
+    if pi % 2 == 0:
+      ds.extend(tl)                       # host rows: pinned record staging + H2D copy
+    else:                                 # device rows: the scatter kernel (k_ring_push / k_ring_push16)
+      cols = []
+      for ci, f in enumerate(zip(*tl)):
+        a = torch.from_numpy(np.asarray(f))
+        a = a if (u8 and ci in (0, 3)) else a.float()
+        cols.append((a.unsqueeze(-1) if a.dim() == 1 else a).to(DEV))
+      TensorTupleDataset.extend(ds, *cols)
     ref.extend_transitions(tl)
     assert len(ds) == len(ref)
     n = len(ref)

@@ -401,7 +401,8 @@ extern "C" int trl_ring_push(void *ring, int64_t capacity, int64_t stride, const
   const bool all16 = stride % 16 == 0 && (uintptr_t)ring % 16 == 0 && stride >= 256;
   for (int c = 0; c < layout->ncols; ++c) {
     TRL_REQUIRE(src[c] != nullptr, "%s: src[%d] is null", fn, c);
-    TRL_REQUIRE((uintptr_t)src[c] % 4 == 0, "%s: src[%d] must be 4-byte aligned", fn, c);
+    TRL_REQUIRE(layout->col_bytes[c] % 4 != 0 || (uintptr_t)src[c] % 4 == 0,
+                "%s: src[%d] must be 4-byte aligned (its rows are read as dwords)", fn, c);
     a.off_dw[c] = layout->col_off[c] / 4;
     a.w_bytes[c] = layout->col_bytes[c];
     a.sdt[c] = a.odt[c] = layout->col_dtype[c];

@@ -104,6 +104,7 @@ class TensorTupleDataset(Dataset):
     self._head = 0
     self._count = 0
     self._pin = None
+    self._stage = None
     if x is not None:
       self.extend(*x)
 
@@ -196,26 +197,81 @@ class TensorTupleDataset(Dataset):
     if self.size <= 0 and self._count + k > self._capacity:
       self._grow(self._count + k)
 
-    src = []
-    for t, sdt in zip(tensors, self._layout.storage_dtypes):
-      t = t.reshape(k, -1)
-      if t.dtype != sdt:
-        t = t.to(sdt)
-      src.append(t.to(self._device, non_blocking=True).contiguous())
     tail = (self._head + self._count) % self._capacity
-    srcp = (C.c_void_p * len(src))(*[s.data_ptr() for s in src])
-    with torch.cuda.device(self._device):
-      _lib.check(_lib.lib().trl_ring_push(self._ring.data_ptr(), self._capacity, self._layout.stride,
-                                          C.byref(self._layout.c), tail, srcp, k,
-                                          _lib.stream_ptr(self._device)))
-    for s in src:   # keep staging alive until the stream has consumed it
-      s.record_stream(torch.cuda.current_stream(self._device))
+    if all(not t.is_cuda for t in tensors):
+      self._push_host(tensors, k, tail)
+    else:
+      self._push_device(tensors, k, tail)
     over = self._count + k - self._capacity
     if over > 0:
       self._head = (self._head + over) % self._capacity
       self._count = self._capacity
     else:
       self._count += k
+
+  def _push_device(self, tensors, k, tail):
+    """Rows already on a device (or mixed): scatter kernel from dense per-column sources."""
+    src = []
+    for t, sdt in zip(tensors, self._layout.storage_dtypes):
+      t = t.reshape(k, -1)
+      if t.dtype != sdt:
+        t = t.to(sdt)
+      t = t.to(self._device, non_blocking=True).contiguous()
+      if t.data_ptr() % 16:     # a slice of the caller's tensor: the kernel wants aligned rows
+        t = t.clone()
+      src.append(t)
+    srcp = (C.c_void_p * len(src))(*[s.data_ptr() for s in src])
+    with torch.cuda.device(self._device):
+      _lib.check(_lib.lib().trl_ring_push(self._ring.data_ptr(), self._capacity, self._layout.stride,
+                                          C.byref(self._layout.c), tail, srcp, k,
+                                          _lib.stream_ptr(self._device)))
+    for s_ in src:   # keep staging alive until the stream has consumed it
+      s_.record_stream(torch.cuda.current_stream(self._device))
+
+  _STAGE_BYTES = 32 << 20
+
+  def _push_host(self, tensors, k, tail):
+    """Rows that are host data (what store() hands over every env step, examples/dqn.py:27-28):
+    packed on the host straight into the ring's record layout in pinned memory and moved with
+    ONE async H2D copy into the ring (two when the write wraps) -- no per-column copies, no
+    kernel.  Large pushes go in slices of the pinned staging size."""
+    st = self._layout.stride
+    rows_per = max(1, self._STAGE_BYTES // st)
+    cols = []
+    for t, sdt in zip(tensors, self._layout.storage_dtypes):
+      t = t.reshape(k, -1)
+      cols.append((t if t.dtype == sdt else t.to(sdt)).contiguous().numpy())
+    ring2d = self._ring.view(self._capacity, st)
+    if self._stage is None:
+      nbytes = min(self._STAGE_BYTES, max(1 << 16, 1 << (k * st - 1).bit_length()))
+      self._stage = [torch.empty(max(nbytes, st), dtype=torch.uint8).pin_memory() for _ in range(4)]
+      self._stage_ev = [None] * 4
+      self._stage_next = 0
+    for lo in range(0, k, rows_per):
+      n = min(rows_per, k - lo)
+      if self._stage[0].numel() < n * st:        # grow (rare): the pushes got bigger
+        for ev in self._stage_ev:
+          if ev is not None:
+            ev.synchronize()
+        nbytes = min(max(self._STAGE_BYTES, st), 1 << (n * st - 1).bit_length())
+        self._stage = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
+        self._stage_ev = [None] * 4
+      slot = self._stage_next
+      self._stage_next = (slot + 1) % 4
+      if self._stage_ev[slot] is not None:
+        self._stage_ev[slot].synchronize()       # the copy issued four pushes ago
+      rec = self._stage[slot][:n * st].view(n, st)
+      recn = rec.numpy()
+      for a, off, nb in zip(cols, self._layout.offsets, self._layout.col_bytes):
+        recn[:, off:off + nb] = a[lo:lo + n].view(np.uint8).reshape(n, nb)
+      t0 = (tail + lo) % self._capacity
+      first = min(n, self._capacity - t0)
+      ring2d[t0:t0 + first].copy_(rec[:first], non_blocking=True)
+      if first < n:
+        ring2d[:n - first].copy_(rec[first:], non_blocking=True)
+      ev = torch.cuda.Event()
+      ev.record(torch.cuda.current_stream(self._device))
+      self._stage_ev[slot] = ev
 
   # ------------------------------------------------------------------ gather
   def _out_dtypes(self):
