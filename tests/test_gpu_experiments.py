@@ -88,3 +88,27 @@ def test_rollout_buffer_matches_per_env_reference_path():
   assert sizes == [32, 32, 32, 19]
   roll.truncate()
   assert len(roll) == 0
+
+
+def test_act_device_distribution_and_shapes():
+  """f3: on-device exploration keeps the reference's action distribution (not its draws)."""
+  from torchrl_amd.contrib.controllers import DQNController, DDPGController, A2CController
+  dev = 'cuda:0'
+  torch.manual_seed(0)
+  c = DQNController(4, 4, eps_max=0.4, eps_min=0.4, device=dev)
+  obs = torch.zeros(20000, 4, device=dev)
+  with torch.no_grad():
+    greedy = int(c.q_net(obs[:1]).argmax())
+  a = c.act_device(obs)
+  assert a.is_cuda and a.dtype == torch.int64 and a.shape == (20000,)
+  freq = torch.bincount(a, minlength=4).float() / 20000
+  for i in range(4):
+    exp = 0.1 + (0.6 if i == greedy else 0.0)            # eps/A (+ 1 - eps for the greedy action)
+    assert abs(float(freq[i]) - exp) < 0.02
+  d = DDPGController(3, 2, -2.0, 2.0, device=dev, n_reset_interval=5)
+  for _ in range(7):
+    act = d.act_device(torch.randn(6, 3, device=dev))
+  assert act.is_cuda and act.shape == (6, 2) and float(act.abs().max()) <= 2.0 and d.noise.step == 2
+  p = PPOController(3, 2, device=dev)
+  assert p.act_device(torch.randn(5, 3, device=dev)).shape == (5, 2)
+  assert A2CController(4, 3, device=dev).act_device(torch.randn(5, 4, device=dev)).shape == (5,)

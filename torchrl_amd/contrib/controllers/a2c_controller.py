@@ -31,6 +31,12 @@ class A2CController(Controller):
       _, dist = self.ac_net(obs_to_tensor(obs, self.device))
     return dist.sample().cpu().numpy()
 
+  def act_device(self, obs):
+    """act() without the `.cpu().numpy()` host sync: the sampled actions as a device tensor."""
+    with torch.no_grad():
+      _, dist = self.ac_net(obs_to_tensor(obs, self.device))
+      return dist.sample()
+
   def compute_return(self, obs, action, reward, next_obs, done):  # pylint: disable=unused-argument
     """One env's rollout [T, .] -> returns [T, 1] (a2c_controller.py:29-45)."""
     return self.compute_return_batched(obs.unsqueeze(1), reward.reshape(-1, 1),

@@ -91,6 +91,28 @@ class DDPGController(Controller):
       self.noise.reset()
     return action
 
+  def act_device(self, obs):
+    """act() kept on the device (ddpg_controller.py:87-99): the OU state lives in a device tensor
+    and its Gaussian increments come from the device generator; returns a float32 device tensor
+    [n, A].  Same process (theta, sigma schedule, reset interval, clipping) as act(), different
+    random stream."""
+    obs = obs_to_tensor(obs, self.device)
+    noise = self.noise
+    with torch.no_grad():
+      action = self.actor(obs)
+      if getattr(self, '_ou_dev', None) is None or noise.step == 0:
+        self._ou_dev = torch.full((noise.action_dim,), float(noise.mu), device=self.device)
+      x = self._ou_dev
+      self._ou_dev = x + (noise.theta * (noise.mu - x) + noise.sigma * torch.randn_like(x))
+      noise.sigma = noise.max_sigma - (noise.max_sigma - noise.min_sigma) * min(1.0, noise.step / noise.decay_period)
+      noise.step += 1
+      low = torch.as_tensor(self.action_low, dtype=torch.float32, device=self.device)
+      high = torch.as_tensor(self.action_high, dtype=torch.float32, device=self.device)
+      action = torch.minimum(torch.maximum(action + self._ou_dev, low), high)
+    if noise.step % self.n_reset_interval == 0:
+      noise.reset()
+    return action
+
   def _learn_body(self, obs, action, reward, next_obs, done):
     actor_loss = -self.critic(obs, self.actor(obs)).mean()
 

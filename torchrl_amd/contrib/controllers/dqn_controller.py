@@ -61,6 +61,19 @@ class DQNController(Controller):
     actions = epsilon_greedy(self.action_size, greedy, self.eps.value)
     return [a[0] for a in actions]
 
+  def act_device(self, obs):
+    """act() without the device -> host round trip (dqn_controller.py:57-59): epsilon-greedy drawn
+    with the device generator, actions returned as an int64 device tensor [n].  Same action
+    distribution as act() (greedy w.p. 1 - eps + eps/A, any other action w.p. eps/A); the draws
+    themselves differ because the reference uses numpy's global generator on the host."""
+    obs = obs_to_tensor(obs, self.device)
+    with torch.no_grad():
+      greedy = self.q_net(obs).argmax(dim=-1)
+      eps = self.eps.value
+      explore = torch.rand(greedy.shape, device=self.device) < eps
+      uniform = torch.randint(0, self.action_size, greedy.shape, device=self.device)
+      return torch.where(explore, uniform, greedy)
+
   def _learn_body(self, obs, action, reward, next_obs, done):
     q = self.q_net(obs)
     with torch.no_grad():

@@ -38,6 +38,12 @@ class PPOController(Controller):
       _, dist = self.ac_net(obs_to_tensor(obs, self.device))
     return dist.sample().cpu().numpy()
 
+  def act_device(self, obs):
+    """act() without the `.cpu().numpy()` host sync: the sampled actions as a device tensor."""
+    with torch.no_grad():
+      _, dist = self.ac_net(obs_to_tensor(obs, self.device))
+      return dist.sample()
+
   def compute_return(self, obs, action, reward, next_obs, done):
     """One env's rollout [T, .] -> (returns [T, 1], log_probs [T, A], values [T, 1])
     (ppo_controller.py:32-51)."""
