@@ -372,8 +372,13 @@ def bench_offpolicy(args, rank, world, dev, atari):
   idx = torch.randint(0, cap, (B,), device=dev, generator=g)
   out = ds._alloc_out(B)
   us = kernel_time_us(lambda: ds._gather_index(idx, out), args.kernel_iters)
-  roof = roofline('k_gather_wide+k_gather_narrow' if atari else 'k_gather_narrow', B * (2 * row_bytes + 8), us,
-                  '(2 x %d B + 8 B) x B=%d' % (row_bytes, B))
+  if atari:   # frames are stored uint8 and handed to the learner as float32 (exact cast in the gather)
+    per_row = (2 * 28224 + 12) + 8 + (2 * 28224 * 4 + 12)
+    roof = roofline('k_gather_wide(u8->f32)+k_gather_narrow', B * per_row, us,
+                    '(%d B u8 record read + 8 B index + %d B f32 batch written) x B=%d'
+                    % (2 * 28224 + 12, 2 * 28224 * 4 + 12, B))
+  else:
+    roof = roofline('k_gather_narrow', B * (2 * row_bytes + 8), us, '(2 x %d B + 8 B) x B=%d' % (row_bytes, B))
   res = {
       'metric': 'learner transitions/sec (sample+loss+update)', 'value': round(value, 1), 'unit': 'transitions/s',
       'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
