@@ -183,9 +183,9 @@ def test_dqn_controller_learn_golden(golden, graph):
       batch = [t(g['%sstep%d_%s' % (p, step, f)], DEV) for f in FIELDS]
       info = c.learn(*batch)
       _loss_close(info['td_loss'].cpu(), g['%sstep%d_td_loss' % (p, step)], atol=0)
-      _vec_close(sub(c._q.grad.cpu().numpy()), g['%sstep%d_grad' % (p, step)])
-      _vec_close(sub(c._q.data.cpu().numpy()), g['%sstep%d_q' % (p, step)], atol_frac=2e-6)
-      _vec_close(sub(c._target.data.cpu().numpy()), g['%sstep%d_t' % (p, step)], atol_frac=2e-6)
+      _vec_close(sub(c._q.dense(grad=True).cpu().numpy()), g['%sstep%d_grad' % (p, step)])
+      _vec_close(sub(c._q.dense().cpu().numpy()), g['%sstep%d_q' % (p, step)], atol_frac=2e-6)
+      _vec_close(sub(c._target.dense().cpu().numpy()), g['%sstep%d_t' % (p, step)], atol_frac=2e-6)
 
 
 @pytest.mark.parametrize('graph', [False, True])
@@ -204,11 +204,11 @@ def test_ddpg_controller_learn_golden(golden, graph):
       info = c.learn(*batch)
       _loss_close(info['actor_loss'].cpu(), g['%sstep%d_actor_loss' % (p, step)], atol=1e-7)
       _loss_close(info['critic_loss'].cpu(), g['%sstep%d_critic_loss' % (p, step)], atol=0)
-      _vec_close(sub(c._actor.grad.cpu().numpy()), g['%sstep%d_actor_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
-      _vec_close(sub(c._critic.grad.cpu().numpy()), g['%sstep%d_critic_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
+      _vec_close(sub(c._actor.dense(grad=True).cpu().numpy()), g['%sstep%d_actor_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
+      _vec_close(sub(c._critic.dense(grad=True).cpu().numpy()), g['%sstep%d_critic_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
       for nm, f in (('actor', c._actor), ('critic', c._critic), ('target_actor', c._target_actor),
                     ('target_critic', c._target_critic)):
-        _vec_close(sub(f.data.cpu().numpy()), g['%sstep%d_%s' % (p, step, nm)], atol_frac=1e-5)
+        _vec_close(sub(f.dense().cpu().numpy()), g['%sstep%d_%s' % (p, step, nm)], atol_frac=1e-5)
 
 
 @pytest.mark.parametrize('graph', [False, True])
@@ -224,8 +224,8 @@ def test_a2c_controller_learn_golden(golden, graph):
       info = c.learn(*batch)
       for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
         _loss_close(info[k].cpu(), g['%sstep%d_%s' % (p, step, k)])
-      _vec_close(c._flat.grad.cpu().numpy(), g['%sstep%d_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
-      _vec_close(c._flat.data.cpu().numpy(), g['%sstep%d_net' % (p, step)], atol_frac=1e-5)
+      _vec_close(c._flat.dense(grad=True).cpu().numpy(), g['%sstep%d_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
+      _vec_close(c._flat.dense().cpu().numpy(), g['%sstep%d_net' % (p, step)], atol_frac=1e-5)
 
 
 @pytest.mark.parametrize('graph', [False, True])
@@ -243,8 +243,8 @@ def test_ppo_controller_learn_golden(golden, graph):
       info = c.learn(*batch)
       for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
         _loss_close(info[k].cpu(), g['%sstep%d_%s' % (p, step, k)])
-      _vec_close(c._flat.grad.cpu().numpy(), g['%sstep%d_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
-      _vec_close(c._flat.data.cpu().numpy(), g['%sstep%d_net' % (p, step)], atol_frac=1e-5)
+      _vec_close(c._flat.dense(grad=True).cpu().numpy(), g['%sstep%d_grad' % (p, step)], rtol=1e-4, atol_frac=1e-5)
+      _vec_close(c._flat.dense().cpu().numpy(), g['%sstep%d_net' % (p, step)], atol_frac=1e-5)
 
 
 def test_split_k_linear_matches_nn_linear():

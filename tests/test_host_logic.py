@@ -118,10 +118,9 @@ def test_controllers_construct_and_act_on_cpu_but_refuse_to_learn():
   # target nets start as copies (dqn_controller.py:37)
   assert torch.equal(d._q.data, d._target.data) and d._q.data.data_ptr() != d._target.data.data_ptr()
   # parameters are views of the flat buffer, in parameters() order
-  off = 0
-  for prm in d.q_net.parameters():
-    assert prm.data_ptr() == d._q.data.data_ptr() + 4 * off
-    off += prm.numel()
+  for prm, off in zip(d.q_net.parameters(), d._q.offsets):
+    assert prm.data_ptr() == d._q.data.data_ptr() + 4 * off and off % 4 == 0   # 16 B-aligned starts
+  assert torch.equal(d._q.dense(), torch.cat([p_.data.reshape(-1) for p_ in d.q_net.parameters()]))
 
 
 def test_storage_without_device_fails_loudly():

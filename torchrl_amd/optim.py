@@ -28,29 +28,35 @@ class FlatParams:
     for p in self.params:
       if p.dtype != torch.float32 or p.device != dev:
         raise TypeError('FlatParams needs float32 parameters on one device')
-    n = sum(p.numel() for p in self.params)
-    self.data = torch.empty(n, dtype=torch.float32, device=dev)
+    # every parameter starts on a 16 B boundary (kernels then take 16 B loads of weight rows);
+    # the padding floats carry zero weights / zero gradients and never move
+    self.offsets, n = [], 0
+    for p in self.params:
+      self.offsets.append(n)
+      n += (p.numel() + 3) // 4 * 4
+    self.data = torch.zeros(n, dtype=torch.float32, device=dev)
     self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-    off = 0
     with torch.no_grad():
-      for p in self.params:
+      for p, off in zip(self.params, self.offsets):
         k = p.numel()
         self.data[off:off + k].copy_(p.data.reshape(-1))
         p.data = self.data[off:off + k].view(p.shape)
         p.grad = self.grad[off:off + k].view(p.shape)
-        off += k
     self.numel = n
     self.device = dev
+
+  def dense(self, grad=False):
+    """The parameters (or gradients) concatenated without the alignment padding, in
+    `module.parameters()` order: what torch.cat over the reference's parameters gives."""
+    buf = self.grad if grad else self.data
+    return torch.cat([buf[off:off + p.numel()] for p, off in zip(self.params, self.offsets)])
 
   def zero_grad(self):
     """Zero in place: the .grad views must survive (autograd then accumulates into them)."""
     self.grad.zero_()
-    off = 0
-    for p in self.params:        # re-attach a view a caller dropped (p.grad = None) or replaced
-      k = p.numel()
+    for p, off in zip(self.params, self.offsets):   # re-attach a view a caller dropped or replaced
       if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
-        p.grad = self.grad[off:off + k].view(p.shape)
-      off += k
+        p.grad = self.grad[off:off + p.numel()].view(p.shape)
 
   def copy_from(self, other):
     """Hard sync: load_state_dict of an identically shaped module (dqn_controller.py:86)."""
