@@ -209,6 +209,29 @@ int64_t trl_linear_bwd_workspace_bytes(int64_t B, int32_t K, int32_t N);
 int trl_linear_bwd(const float *dy, const float *y, const float *x, const float *w, int64_t B, int32_t K,
                    int32_t N, int32_t act, float *dx, float *dw, float *db, void *ws, void *stream);
 
+/* A whole MLP (Linear -> ReLU -> ... -> Linear, 1..3 Linear layers, every fan-in / fan-out
+ * <= 64, e.g. the "MLP 64x64" of the PPO benchmark) in ONE forward launch and ONE backward
+ * launch (+ a small reduce): the activations go from layer to layer through LDS.
+ *   dims[0] = fan-in of the net, dims[l+1] = fan-out of layer l; w[l] is [dims[l+1], dims[l]].
+ *   fwd: acts[l] ([B, dims[l+1]], caller-owned) receives the output of layer l (post-ReLU for the
+ *        hidden layers, plain for the last): acts[depth-1] is the network output, the others
+ *        are what the backward needs.
+ *   bwd: dy [B, dims[depth]] is the gradient w.r.t. the network output; `grads` receives the
+ *        parameter gradients densely in the order dW_0, db_0, dW_1, db_1, ... (OVERWRITTEN).
+ *        No gradient w.r.t. x is produced (the nets' inputs are observations).
+ * `ws`: trl_mlp_bwd_workspace_bytes(net, B) bytes of device scratch. */
+typedef struct {
+  int32_t depth;
+  int32_t dims[4];
+  const float *w[3];
+  const float *b[3];
+} trl_mlp_desc;
+
+int trl_mlp_fwd(const trl_mlp_desc *net, const float *x, int64_t B, float *const *acts, void *stream);
+int64_t trl_mlp_bwd_workspace_bytes(const trl_mlp_desc *net, int64_t B);
+int trl_mlp_bwd(const trl_mlp_desc *net, const float *x, const float *const *acts, const float *dy, int64_t B,
+                float *grads, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,56 @@ def test_mlp_container_fused_equals_plain(monkeypatch):
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('dims,B', [((3, 64, 64, 1), 65536), ((3, 64, 64, 2), 9000), ((4, 64, 6), 8200),
+                                    ((17, 33, 5), 10000), ((64, 64, 64, 64), 8192), ((3, 2), 12345),
+                                    ((8, 1, 1, 1), 9999)])
+def test_whole_network_kernels_match_torch(dims, B):
+  """mlp64: forward output and every parameter gradient vs torch's Linear/ReLU stack."""
+  g = torch.Generator(device=DEV).manual_seed(sum(dims) + B)
+  layers = []
+  for i in range(len(dims) - 1):
+    layers.append(torch.nn.Linear(dims[i], dims[i + 1]))
+    if i + 2 < len(dims):
+      layers.append(torch.nn.ReLU())
+  ref = torch.nn.Sequential(*layers).to(DEV)
+  lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+  x = torch.randn(B, dims[0], device=DEV, generator=g)
+  gy = torch.randn(B, dims[-1], device=DEV, generator=g)
+  y1 = ref(x)
+  y1.backward(gy)
+  exp = [p.grad.clone() for p in ref.parameters()]
+  ref.zero_grad(set_to_none=True)
+  y2 = F.mlp64(x, [m.weight for m in lin], [m.bias for m in lin])
+  torch.testing.assert_close(y2, y1, rtol=1e-5, atol=1e-5)
+  y2.backward(gy)
+  for p, e in zip(ref.parameters(), exp):
+    torch.testing.assert_close(p.grad, e, rtol=1e-4, atol=2e-5 * max(1.0, float(e.abs().max())))
+
+
+def test_mlp_container_uses_whole_network_path_and_matches(monkeypatch):
+  torch.manual_seed(1)
+  net = models.ActorCriticNet(3, 2, (64, 64)).to(DEV)
+  x = torch.randn(20000, 3, device=DEV)
+  out = {}
+  for mode in ('1', '0'):
+    monkeypatch.setenv('TRL_FUSED_MLP', mode)
+    net.zero_grad()
+    v, mean, _ = net.heads(x)
+    (v.sum() + (mean * mean).sum()).backward()
+    out[mode] = (v.detach().clone(), mean.detach().clone(),
+                 [p.grad.clone() for p in net.parameters() if p.grad is not None])
+  torch.testing.assert_close(out['1'][0], out['0'][0], rtol=1e-5, atol=1e-5)
+  torch.testing.assert_close(out['1'][1], out['0'][1], rtol=1e-5, atol=1e-5)
+  for a, b in zip(out['1'][2], out['0'][2]):
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+  # DDPG's tanh tail stays on torch, after the fused stack
+  actor = models.DDPGActorNet(3, 1, 64).to(DEV)
+  monkeypatch.setenv('TRL_FUSED_MLP', '1')
+  a1 = actor(x)
+  monkeypatch.setenv('TRL_FUSED_MLP', '0')
+  torch.testing.assert_close(a1, actor(x), rtol=1e-5, atol=1e-6)
+
+
 def test_bad_arguments():
   x = torch.zeros(8, 4, device=DEV)
   with pytest.raises(Exception):

@@ -31,6 +31,11 @@ class AdamState(C.Structure):
               ('derived', C.c_float * 8)]
 
 
+class MlpDesc(C.Structure):
+  """mirror of trl_mlp_desc"""
+  _fields_ = [('depth', C.c_int32), ('dims', C.c_int32 * 4), ('w', C.c_void_p * 3), ('b', C.c_void_p * 3)]
+
+
 class TrlError(RuntimeError):
   pass
 
@@ -62,6 +67,9 @@ PROTOTYPES = {
     'trl_linear_fwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     'trl_linear_bwd_workspace_bytes': (_i64, [_i64, _i32, _i32]),
     'trl_linear_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'trl_mlp_fwd': (C.c_int, [C.POINTER(MlpDesc), _vp, _i64, C.POINTER(_vp), _vp]),
+    'trl_mlp_bwd_workspace_bytes': (_i64, [C.POINTER(MlpDesc), _i64]),
+    'trl_mlp_bwd': (C.c_int, [C.POINTER(MlpDesc), _vp, C.POINTER(_vp), _vp, _i64, _vp, _vp, _vp]),
 }
 
 _lib = None

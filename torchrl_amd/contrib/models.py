@@ -85,6 +85,9 @@ class _Mlp(nn.Sequential):
             and _fused_mlp_enabled()):
       return super().forward(x)
     mods = list(self)
+    whole = self._whole_net(mods, x)
+    if whole is not None:
+      return whole
     i = 0
     while i < len(mods):
       m = mods[i]
@@ -97,6 +100,34 @@ class _Mlp(nn.Sequential):
         x = m(x)
         i += 1
     return x
+
+
+def _whole_net(self, mods, x):
+  """Linear/ReLU alternation of <= 3 Linear layers, all <= 64 wide, input without gradient:
+  one fused forward launch (and one backward launch) for the whole stack; any trailing
+  non-Linear modules (Tanh, Softmax) are applied by torch afterwards."""
+  if x.requires_grad:
+    return None
+  lin, i = [], 0
+  while i < len(mods) and isinstance(mods[i], nn.Linear):
+    lin.append(mods[i])
+    i += 1
+    if i < len(mods) and isinstance(mods[i], nn.ReLU) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Linear):
+      i += 1
+    else:
+      break
+  tail = mods[i:]
+  if not (1 <= len(lin) <= 3) or any(isinstance(m, (nn.Linear, nn.ReLU)) for m in tail):
+    return None
+  if any(m.bias is None or max(m.in_features, m.out_features) > 64 for m in lin):
+    return None
+  y = _F.mlp64(x, [m.weight for m in lin], [m.bias for m in lin])
+  for m in tail:
+    y = m(y)
+  return y
+
+
+_Mlp._whole_net = _whole_net
 
 
 def _fused_mlp_enabled():

@@ -19,6 +19,8 @@
 // launch in slab order: bitwise reproducible run to run (no float atomics).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "trl_common.h"
 
 namespace {
@@ -317,6 +319,246 @@ __global__ __launch_bounds__(256) void k_linear_bwd_reduce(const float *__restri
   }
 }
 
+// ==========================================================================================
+// Whole-network kernels for MLPs whose layers are all at most 64 wide (fan-in and fan-out):
+// Linear -> ReLU -> ... -> Linear, 1..3 Linear layers.  One launch runs the forward of every
+// layer for a 128-row tile with the activations handed from layer to layer through LDS (they
+// are also written out once, for the backward); one launch runs the whole backward for a slab
+// of tiles: per layer dW += g^T a, db += colsum g, g <- (g W) * (a > 0), with g and the layer
+// input a in LDS and every layer's dW partial in registers across the slab's tiles.  Compared
+// with one launch pair per layer this removes the per-launch latency floor (~10 us each at
+// these sizes) and the re-reads of g between layers.  Every layer is treated as 64x64 with zero
+// padding (NB = KB = 2): padded weight rows/columns are zero, so padded activations are zero.
+struct MlpArgs {
+  int32_t depth;             // number of Linear layers, 1..3
+  int32_t dims[4];           // dims[0] = fan-in of the net, dims[l+1] = fan-out of layer l (all <= 64)
+  const float *w[3];         // [dims[l+1], dims[l]] row-major
+  const float *b[3];
+  float *act[3];             // forward: out; backward: in.  act[l] = output of layer l, [B, dims[l+1]]
+  int32_t vec[4];            // vec[l]: rows of width dims[l] are 16 B-loadable (dims % 4 == 0, aligned bases)
+};
+
+constexpr int LDA = 65;      // LDS row stride of every 128 x 64 / 64 x 64 tile
+
+template <bool VEC, int ROWS>
+__device__ __forceinline__ void stage64(float *s, const float *__restrict__ m, int64_t rows, int ld, int64_t row0) {
+  TileRegs<64, VEC, ROWS> r;
+  r.load(m, rows, ld, row0, 0);
+  r.template store<LDA>(s);
+}
+
+__global__ __launch_bounds__(256) void k_mlp_fwd(const float *__restrict__ x, int64_t B, MlpArgs a) {
+  __shared__ float sA[2][BM * LDA];
+  __shared__ float sW[64 * LDA];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row0 = (int64_t)blockIdx.x * BM;
+  if (a.vec[0]) stage64<true, BM>(sA[0], x, B, a.dims[0], row0);
+  else stage64<false, BM>(sA[0], x, B, a.dims[0], row0);
+  int cur = 0;
+  for (int l = 0; l < a.depth; ++l) {
+    const int K = a.dims[l], N = a.dims[l + 1];
+    __syncthreads();                      // sW free (previous layer's MFMAs done); sA[cur] complete
+    if (a.vec[l]) stage64<true, 64>(sW, a.w[l], N, K, 0);
+    else stage64<false, 64>(sW, a.w[l], N, K, 0);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const float *sa = sA[cur];
+    const int kmax = (K + 1) & ~1;
+#pragma unroll 4
+    for (int kk = 0; kk < kmax; kk += 2) {
+      const float av = sa[(wave * 32 + (lane & 31)) * LDA + kk + (lane >> 5)];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float bv = sW[(nb * 32 + (lane & 31)) * LDA + kk + (lane >> 5)];
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+      }
+    }
+    const bool relu = l + 1 < a.depth;
+    float *sn = sA[cur ^ 1];
+    float *out = a.act[l];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int col = nb * 32 + (lane & 31);
+      const float bias = col < N ? a.b[l][col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wave * 32 + cd_row(r, lane);
+        float v = acc[nb][r] + bias;
+        if (relu) v = v > 0.f ? v : 0.f;
+        sn[lr * LDA + col] = v;             // next layer's operand (padded columns are exactly 0)
+        const int64_t gr = row0 + lr;
+        if (gr < B && col < N) out[gr * N + col] = v;
+      }
+    }
+    cur ^= 1;
+  }
+}
+
+// ws_part[slab] holds the slab's parameter-gradient partials, densely: for l = 0..depth-1:
+// dW_l [dims[l+1] * dims[l]] then db_l [dims[l+1]].
+__global__ __launch_bounds__(256) void k_mlp_bwd(const float *__restrict__ x, const float *__restrict__ dy,
+                                                 int64_t B, MlpArgs a, int tiles_per_slab, int nparams,
+                                                 float *__restrict__ ws_part) {
+  __shared__ float sG[BM * LDA];     // gradient w.r.t. the current layer's output (masked)
+  __shared__ float sAct[BM * LDA];   // the current layer's input activation
+  __shared__ float sW[64 * LDA];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slab = blockIdx.x;
+  const int64_t ntiles = (B + BM - 1) / BM;
+  const int64_t tile_lo = (int64_t)slab * tiles_per_slab;
+  int64_t tile_hi = tile_lo + tiles_per_slab;
+  if (tile_hi > ntiles) tile_hi = ntiles;
+
+  f32x16 accW[3][2][2];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[l][nb][kb][r] = 0.f;
+  float dbacc[3] = {0.f, 0.f, 0.f};   // thread t: column t & 63, rows of group t >> 6
+  const int D = a.depth;
+
+  for (int64_t tile = tile_lo; tile < tile_hi; ++tile) {
+    const int64_t row0 = tile * BM;
+    __syncthreads();                   // the previous tile's readers of sG / sAct are done
+    if (a.vec[D]) stage64<true, BM>(sG, dy, B, a.dims[D], row0);
+    else stage64<false, BM>(sG, dy, B, a.dims[D], row0);
+    // layers from the last to the first; `li` is a compile-time constant so that accW[li] stays in registers
+    auto layer = [&](auto li_c) {
+      constexpr int li = decltype(li_c)::value;
+      const int l = D - 1 - li;
+      if (l < 0) return;
+      const int K = a.dims[l], N = a.dims[l + 1];
+      const float *ain = l > 0 ? a.act[l - 1] : x;
+      if (a.vec[l]) stage64<true, BM>(sAct, ain, B, K, row0);
+      else stage64<false, BM>(sAct, ain, B, K, row0);
+      if (l > 0) {
+        if (a.vec[l]) stage64<true, 64>(sW, a.w[l], N, K, 0);
+        else stage64<false, 64>(sW, a.w[l], N, K, 0);
+      }
+      __syncthreads();
+      {   // db_l: column sums of g
+        const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) sum += sG[(grp * 32 + r) * LDA + c];
+        dbacc[li] += sum;
+      }
+      // dW_l += g^T a   (rows of this wave)
+      const int nmax_b = (N + 31) >> 5, kmax_b = (K + 31) >> 5;   // skip all-zero 32-blocks
+#pragma unroll 4
+      for (int r2 = 0; r2 < 32; r2 += 2) {
+        const int row = wave * 32 + r2 + (lane >> 5);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          if (nb < nmax_b) {
+            const float av = sG[row * LDA + nb * 32 + (lane & 31)];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              if (kb < kmax_b) {
+                const float bv = sAct[row * LDA + kb * 32 + (lane & 31)];
+                accW[li][nb][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accW[li][nb][kb], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      if (l > 0) {   // g <- (g @ W_l) * (a > 0)
+        f32x16 accX[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accX[kb][r] = 0.f;
+        const int nmax = (N + 1) & ~1;
+#pragma unroll 4
+        for (int n2 = 0; n2 < nmax; n2 += 2) {
+          const float av = sG[(wave * 32 + (lane & 31)) * LDA + n2 + (lane >> 5)];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const float bv = sW[(n2 + (lane >> 5)) * LDA + kb * 32 + (lane & 31)];
+            accX[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accX[kb], 0, 0, 0);
+          }
+        }
+        __syncthreads();               // every reader of the old g is done
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int col = kb * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = wave * 32 + cd_row(r, lane);
+            sG[lr * LDA + col] = sAct[lr * LDA + col] > 0.f ? accX[kb][r] : 0.f;
+          }
+        }
+        __syncthreads();               // new g complete; sAct / sW free for the next layer
+      }
+    };
+    layer(std::integral_constant<int, 0>{});
+    layer(std::integral_constant<int, 1>{});
+    layer(std::integral_constant<int, 2>{});
+  }
+
+  // ---- per layer: add the four waves' dW partials in wave order through LDS, write the slab's partial
+  float *part = ws_part + (int64_t)slab * nparams;
+  auto flush = [&](auto li_c) {
+    constexpr int li = decltype(li_c)::value;
+    const int l = D - 1 - li;
+    if (l < 0) return;
+    const int K = a.dims[l], N = a.dims[l + 1];
+    int loff = 0;                      // offset of layer l in the dense parameter order
+    for (int j = 0; j < l; ++j) loff += a.dims[j + 1] * a.dims[j] + a.dims[j + 1];
+    for (int wv = 0; wv < 4; ++wv) {
+      __syncthreads();
+      if (wave == wv) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int idx = (nb * 32 + cd_row(r, lane)) * 64 + kb * 32 + (lane & 31);
+              sG[idx] = wv == 0 ? accW[li][nb][kb][r] : sG[idx] + accW[li][nb][kb][r];
+            }
+      }
+    }
+    // bias partials of the four row groups -> sAct[0..255], summed in group order below
+    sAct[threadIdx.x] = dbacc[li];
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * K; e += 256) part[loff + e] = sG[(e / K) * 64 + (e % K)];
+    if ((int)threadIdx.x < N)
+      part[loff + N * K + threadIdx.x] =
+          ((sAct[threadIdx.x] + sAct[64 + threadIdx.x]) + sAct[128 + threadIdx.x]) + sAct[192 + threadIdx.x];
+  };
+  flush(std::integral_constant<int, 0>{});
+  flush(std::integral_constant<int, 1>{});
+  flush(std::integral_constant<int, 2>{});
+}
+
+// grads[i] = sum over slabs of ws_part[slab][i], 16 outputs per block, slabs in a fixed order
+__global__ __launch_bounds__(256) void k_mlp_bwd_reduce(const float *__restrict__ ws_part, int nslabs, int nparams,
+                                                        float *__restrict__ grads) {
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + e;
+  float s = 0.f;
+  if (i < nparams)
+    for (int sl = grp; sl < nslabs; sl += 16) s += ws_part[(int64_t)sl * nparams + i];
+  part[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && i < nparams) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) t += part[g2][e];
+    grads[i] = t;
+  }
+}
+
 constexpr int64_t WS_CAP_BYTES = 128ll << 20;
 constexpr int MAX_SLABS = 256;
 
@@ -409,6 +651,84 @@ extern "C" int trl_linear_bwd(const float *dy, const float *y, const float *x, c
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(k_linear_bwd_reduce, dim3((unsigned)trl_cdiv(nk + N, 16)), dim3(256), 0, st,
                      (const float *)ws_dw, (const float *)ws_db, slabs, nk, (int)N, dw, db);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+namespace {
+int fill_mlp_args(const char *fn, const trl_mlp_desc *net, MlpArgs *a, int *nparams) {
+  TRL_REQUIRE(net != nullptr, "%s: null network description", fn);
+  TRL_REQUIRE(net->depth >= 1 && net->depth <= 3, "%s: depth %d not in [1, 3]", fn, net->depth);
+  a->depth = net->depth;
+  int np = 0;
+  for (int l = 0; l <= net->depth; ++l) {
+    TRL_REQUIRE(net->dims[l] >= 1 && net->dims[l] <= 64, "%s: width dims[%d]=%d must be in [1, 64]", fn, l,
+                net->dims[l]);
+    a->dims[l] = net->dims[l];
+  }
+  for (int l = 0; l < net->depth; ++l) {
+    TRL_REQUIRE(net->w[l] && net->b[l], "%s: null weight/bias of layer %d", fn, l);
+    a->w[l] = net->w[l];
+    a->b[l] = net->b[l];
+    np += net->dims[l + 1] * net->dims[l] + net->dims[l + 1];
+  }
+  *nparams = np;
+  return TRL_OK;
+}
+inline bool rows16(int width, const void *p) { return width % 4 == 0 && (uintptr_t)p % 16 == 0; }
+}  // namespace
+
+extern "C" int trl_mlp_fwd(const trl_mlp_desc *net, const float *x, int64_t B, float *const *acts, void *stream) {
+  const char *fn = "trl_mlp_fwd";
+  MlpArgs a{};
+  int np = 0;
+  int rc = fill_mlp_args(fn, net, &a, &np);
+  if (rc) return rc;
+  TRL_REQUIRE(x && acts, "%s: null pointer", fn);
+  TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
+  for (int l = 0; l < a.depth; ++l) {
+    TRL_REQUIRE(acts[l] != nullptr, "%s: acts[%d] is null", fn, l);
+    a.act[l] = acts[l];
+    a.vec[l] = (l == 0 ? rows16(a.dims[0], x) : rows16(a.dims[l], acts[l - 1])) && rows16(a.dims[l], a.w[l]);
+  }
+  hipLaunchKernelGGL(k_mlp_fwd, dim3((unsigned)trl_cdiv(B, BM)), dim3(256), 0, (hipStream_t)stream, x, B, a);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+extern "C" int64_t trl_mlp_bwd_workspace_bytes(const trl_mlp_desc *net, int64_t B) {
+  if (!net || net->depth < 1 || net->depth > 3 || B <= 0) return 0;
+  int np = 0;
+  for (int l = 0; l < net->depth; ++l) np += net->dims[l + 1] * net->dims[l] + net->dims[l + 1];
+  const int64_t ntiles = trl_cdiv(B, BM);
+  const int64_t slabs = ntiles < MAX_SLABS ? ntiles : MAX_SLABS;
+  return slabs * (int64_t)np * 4;
+}
+
+extern "C" int trl_mlp_bwd(const trl_mlp_desc *net, const float *x, const float *const *acts, const float *dy,
+                           int64_t B, float *grads, void *ws, void *stream) {
+  const char *fn = "trl_mlp_bwd";
+  MlpArgs a{};
+  int np = 0;
+  int rc = fill_mlp_args(fn, net, &a, &np);
+  if (rc) return rc;
+  TRL_REQUIRE(x && acts && dy && grads && ws, "%s: null pointer", fn);
+  TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
+  for (int l = 0; l + 1 < a.depth; ++l) {
+    TRL_REQUIRE(acts[l] != nullptr, "%s: acts[%d] is null", fn, l);
+    a.act[l] = (float *)acts[l];
+  }
+  for (int l = 0; l < a.depth; ++l)
+    a.vec[l] = (l == 0 ? rows16(a.dims[0], x) : rows16(a.dims[l], acts[l - 1])) && rows16(a.dims[l], a.w[l]);
+  a.vec[a.depth] = rows16(a.dims[a.depth], dy);
+  const int64_t ntiles = trl_cdiv(B, BM);
+  const int tps = (int)trl_cdiv(ntiles, ntiles < MAX_SLABS ? ntiles : MAX_SLABS);
+  const int slabs = (int)trl_cdiv(ntiles, tps);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mlp_bwd, dim3((unsigned)slabs), dim3(256), 0, st, x, dy, B, a, tps, np, (float *)ws);
+  TRL_CHECK_LAUNCH(fn);
+  hipLaunchKernelGGL(k_mlp_bwd_reduce, dim3((unsigned)trl_cdiv(np, 16)), dim3(256), 0, st, (const float *)ws, slabs,
+                     np, grads);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
 }

@@ -328,3 +328,66 @@ def linear_act(x, weight, bias, relu=False):
   """act(x @ weight^T + bias) for 2-D float32 device tensors, fan-out <= 256: one HIP launch
   forward, one (+ a small reduce) backward (csrc/trl_mlp.hip)."""
   return _LinearAct.apply(x, weight, bias, 1 if relu else 0)
+
+
+def _mlp_desc(weights, biases):
+  import ctypes as C
+  d = _lib.MlpDesc()
+  d.depth = len(weights)
+  d.dims[0] = weights[0].shape[1]
+  for l, (w, b) in enumerate(zip(weights, biases)):
+    d.dims[l + 1] = w.shape[0]
+    d.w[l] = w.data_ptr()
+    d.b[l] = b.data_ptr()
+  return d
+
+
+class _Mlp64(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, *params):
+    import ctypes as C
+    x = _f32c(x, 'x')
+    weights = [_f32c(p, 'weight') for p in params[0::2]]
+    biases = [_f32c(p, 'bias') for p in params[1::2]]
+    B = x.shape[0]
+    desc = _mlp_desc(weights, biases)
+    acts = [torch.empty((B, w.shape[0]), dtype=torch.float32, device=x.device) for w in weights]
+    actp = (C.c_void_p * len(acts))(*[t.data_ptr() for t in acts])
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().trl_mlp_fwd(C.byref(desc), x.data_ptr(), B, actp, _lib.stream_ptr(x.device)))
+    ctx.depth = len(weights)
+    ctx.save_for_backward(x, *weights, *biases, *acts[:-1])
+    return acts[-1]
+
+  @staticmethod
+  def backward(ctx, dy):
+    import ctypes as C
+    D = ctx.depth
+    saved = ctx.saved_tensors
+    x, weights, biases, acts = saved[0], saved[1:1 + D], saved[1 + D:1 + 2 * D], saved[1 + 2 * D:]
+    dy = dy.contiguous()
+    B = x.shape[0]
+    desc = _mlp_desc(weights, biases)
+    nparams = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
+    grads = torch.empty(nparams, dtype=torch.float32, device=x.device)
+    ws = _linear_ws(x.device, _lib.lib().trl_mlp_bwd_workspace_bytes(C.byref(desc), B))
+    actp = (C.c_void_p * 3)(*([t.data_ptr() for t in acts] + [None] * (3 - len(acts))))
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().trl_mlp_bwd(C.byref(desc), x.data_ptr(), actp, dy.data_ptr(), B, grads.data_ptr(),
+                                        ws.data_ptr(), _lib.stream_ptr(x.device)))
+    out, off = [None], 0
+    for w, b in zip(weights, biases):
+      out.append(grads[off:off + w.numel()].view(w.shape))
+      off += w.numel()
+      out.append(grads[off:off + b.numel()])
+      off += b.numel()
+    return tuple(out)
+
+
+def mlp64(x, weights, biases):
+  """Linear -> ReLU -> ... -> Linear (1..3 Linear layers, every width <= 64) as one forward
+  launch and one backward launch (csrc/trl_mlp.hip: k_mlp_fwd / k_mlp_bwd).  x gets no gradient."""
+  params = []
+  for w, b in zip(weights, biases):
+    params += [w, b]
+  return _Mlp64.apply(x, *params)
