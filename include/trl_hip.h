@@ -218,6 +218,9 @@ int trl_linear_bwd(const float *dy, const float *y, const float *x, const float 
  *        are what the backward needs.
  *   bwd: dy [B, dims[depth]] is the gradient w.r.t. the network output; `grads` receives the
  *        parameter gradients densely in the order dW_0, db_0, dW_1, db_1, ... (OVERWRITTEN).
+ *        Alternatively `param_grads` (2 * depth pointers in that same order, e.g. the .grad
+ *        views of a flat gradient buffer) receives each parameter's gradient directly; pass
+ *        one of the two, the other NULL.
  *        No gradient w.r.t. x is produced (the nets' inputs are observations).
  * `ws`: trl_mlp_bwd_workspace_bytes(net, B) bytes of device scratch. */
 typedef struct {
@@ -230,7 +233,7 @@ typedef struct {
 int trl_mlp_fwd(const trl_mlp_desc *net, const float *x, int64_t B, float *const *acts, void *stream);
 int64_t trl_mlp_bwd_workspace_bytes(const trl_mlp_desc *net, int64_t B);
 int trl_mlp_bwd(const trl_mlp_desc *net, const float *x, const float *const *acts, const float *dy, int64_t B,
-                float *grads, void *ws, void *stream);
+                float *grads, float *const *param_grads, void *ws, void *stream);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,27 @@ def test_mlp_container_uses_whole_network_path_and_matches(monkeypatch):
   torch.testing.assert_close(a1, actor(x), rtol=1e-5, atol=1e-6)
 
 
+def test_direct_grads_equal_autograd_accumulation():
+  """direct_grads=True writes the same numbers into .grad that autograd would accumulate into
+  zeroed gradients (bit for bit: same kernels, same fixed-order sums)."""
+  from torchrl_amd.optim import FlatParams
+  torch.manual_seed(2)
+  net = models.ActorCriticNet(3, 1, (64, 64)).to(DEV)
+  flat = FlatParams(net)
+  x = torch.randn(16384, 3, device=DEV)
+  res = []
+  for direct in (False, True):
+    net.critic.direct_grads = net.actor.direct_grads = direct
+    flat.zero_grad()
+    v, mean, _ = net.heads(x)
+    ((v * v).mean() + mean.sum()).backward()
+    res.append(flat.grad.clone())
+  assert torch.equal(res[0], res[1]) and float(res[0].abs().max()) > 0
+  with pytest.raises(ValueError):
+    w = torch.zeros(2, 3, device=DEV, requires_grad=True)
+    F.mlp64(x, [w], [torch.zeros(2, device=DEV, requires_grad=True)], direct_grads=True)   # no .grad yet
+
+
 def test_bad_arguments():
   x = torch.zeros(8, 4, device=DEV)
   with pytest.raises(Exception):

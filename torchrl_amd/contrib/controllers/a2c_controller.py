@@ -19,6 +19,8 @@ class A2CController(Controller):
     self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._flat)
     self.ac_net_optim = FlatAdam(self._flat, lr=lr, grad_scale=self._sync.scale, device_state=graph)
+    for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
+      stack.direct_grads = True
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma

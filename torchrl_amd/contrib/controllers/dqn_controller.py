@@ -46,6 +46,8 @@ class DQNController(Controller):
     self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._q, self._target)
     self.q_net_optim = FlatAdam(self._q, lr=lr, grad_scale=self._sync.scale, device_state=graph)
+    for stack in (self.q_net.net,):     # one use per backward, zeroed grads: let the fused backward write .grad itself
+      stack.direct_grads = True
     self._run = LearnRunner(self._learn_body, [self.q_net_optim], lambda: [], self.device, graph)
 
     self.double_dqn = double_dqn

@@ -24,6 +24,8 @@ class PPOController(Controller):
     # the data-parallel mean are folded into the Adam launch, i.e. applied after the reduction
     self.ac_net_optim = FlatAdam(self._flat, lr=lr, grad_scale=self._sync.scale, clip_value=max_grad_norm,
                                  device_state=graph)
+    for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
+      stack.direct_grads = True
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma

@@ -121,7 +121,9 @@ def _whole_net(self, mods, x):
     return None
   if any(m.bias is None or max(m.in_features, m.out_features) > 64 for m in lin):
     return None
-  y = _F.mlp64(x, [m.weight for m in lin], [m.bias for m in lin])
+  direct = getattr(self, 'direct_grads', False) and torch.is_grad_enabled() and \
+      all(m.weight.grad is not None and m.bias.grad is not None for m in lin)
+  y = _F.mlp64(x, [m.weight for m in lin], [m.bias for m in lin], direct_grads=direct)
   for m in tail:
     y = m(y)
   return y

@@ -348,17 +348,15 @@ __device__ __forceinline__ void stage64(float *s, const float *__restrict__ m, i
 }
 
 __global__ __launch_bounds__(256) void k_mlp_fwd(const float *__restrict__ x, int64_t B, MlpArgs a) {
-  __shared__ float sA[2][BM * LDA];
-  __shared__ float sW[64 * LDA];
+  __shared__ float sA[BM * LDA];     // the current layer's input; overwritten in place by its output
+  __shared__ float sW[64 * LDA];     // 50 KB in all: three workgroups per CU, so tiles overlap each other's latency
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t row0 = (int64_t)blockIdx.x * BM;
-  if (a.vec[0]) stage64<true, BM>(sA[0], x, B, a.dims[0], row0);
-  else stage64<false, BM>(sA[0], x, B, a.dims[0], row0);
-  int cur = 0;
+  if (a.vec[0]) stage64<true, BM>(sA, x, B, a.dims[0], row0);
+  else stage64<false, BM>(sA, x, B, a.dims[0], row0);
   for (int l = 0; l < a.depth; ++l) {
     const int K = a.dims[l], N = a.dims[l + 1];
-    __syncthreads();                      // sW free (previous layer's MFMAs done); sA[cur] complete
-    if (a.vec[l]) stage64<true, 64>(sW, a.w[l], N, K, 0);
+    if (a.vec[l]) stage64<true, 64>(sW, a.w[l], N, K, 0);   // sW is free: a barrier follows every MFMA loop
     else stage64<false, 64>(sW, a.w[l], N, K, 0);
     __syncthreads();
     f32x16 acc[2];
@@ -366,19 +364,17 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float *__restrict__ x, in
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    const float *sa = sA[cur];
     const int kmax = (K + 1) & ~1;
-#pragma unroll 4
     for (int kk = 0; kk < kmax; kk += 2) {
-      const float av = sa[(wave * 32 + (lane & 31)) * LDA + kk + (lane >> 5)];
+      const float av = sA[(wave * 32 + (lane & 31)) * LDA + kk + (lane >> 5)];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const float bv = sW[(nb * 32 + (lane & 31)) * LDA + kk + (lane >> 5)];
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
       }
     }
+    __syncthreads();                      // every wave is done reading sA and sW
     const bool relu = l + 1 < a.depth;
-    float *sn = sA[cur ^ 1];
     float *out = a.act[l];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -389,12 +385,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float *__restrict__ x, in
         const int lr = wave * 32 + cd_row(r, lane);
         float v = acc[nb][r] + bias;
         if (relu) v = v > 0.f ? v : 0.f;
-        sn[lr * LDA + col] = v;             // next layer's operand (padded columns are exactly 0)
+        sA[lr * LDA + col] = v;             // next layer's operand (padded columns are exactly 0)
         const int64_t gr = row0 + lr;
         if (gr < B && col < N) out[gr * N + col] = v;
       }
     }
-    cur ^= 1;
   }
 }
 
@@ -453,7 +448,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float *__restrict__ x, co
       }
       // dW_l += g^T a   (rows of this wave)
       const int nmax_b = (N + 31) >> 5, kmax_b = (K + 31) >> 5;   // skip all-zero 32-blocks
-#pragma unroll 4
       for (int r2 = 0; r2 < 32; r2 += 2) {
         const int row = wave * 32 + r2 + (lane >> 5);
 #pragma unroll
@@ -477,7 +471,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float *__restrict__ x, co
 #pragma unroll
           for (int r = 0; r < 16; ++r) accX[kb][r] = 0.f;
         const int nmax = (N + 1) & ~1;
-#pragma unroll 4
         for (int n2 = 0; n2 < nmax; n2 += 2) {
           const float av = sG[(wave * 32 + (lane & 31)) * LDA + n2 + (lane >> 5)];
 #pragma unroll
@@ -540,9 +533,17 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const float *__restrict__ x, co
   flush(std::integral_constant<int, 2>{});
 }
 
-// grads[i] = sum over slabs of ws_part[slab][i], 16 outputs per block, slabs in a fixed order
+// out[i] = sum over slabs of ws_part[slab][i], 16 outputs per block, slabs in a fixed order.  The
+// sums go either to one dense array or, parameter by parameter, to caller-given destinations
+// (e.g. the .grad views of a flat gradient buffer), segment j covering [start[j], start[j+1]).
+struct GradDst {
+  int32_t nseg;              // 0: dense output
+  int32_t start[7];
+  float *dst[6];
+};
+
 __global__ __launch_bounds__(256) void k_mlp_bwd_reduce(const float *__restrict__ ws_part, int nslabs, int nparams,
-                                                        float *__restrict__ grads) {
+                                                        float *__restrict__ grads, GradDst gd) {
   __shared__ float part[16][17];
   const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + e;
@@ -555,7 +556,13 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_reduce(const float *__restrict_
     float t = 0.f;
 #pragma unroll
     for (int g2 = 0; g2 < 16; ++g2) t += part[g2][e];
-    grads[i] = t;
+    if (gd.nseg == 0) {
+      grads[i] = t;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (j < gd.nseg && i >= gd.start[j] && i < gd.start[j + 1]) gd.dst[j][i - gd.start[j]] = t;
+    }
   }
 }
 
@@ -706,14 +713,29 @@ extern "C" int64_t trl_mlp_bwd_workspace_bytes(const trl_mlp_desc *net, int64_t 
 }
 
 extern "C" int trl_mlp_bwd(const trl_mlp_desc *net, const float *x, const float *const *acts, const float *dy,
-                           int64_t B, float *grads, void *ws, void *stream) {
+                           int64_t B, float *grads, float *const *param_grads, void *ws, void *stream) {
   const char *fn = "trl_mlp_bwd";
   MlpArgs a{};
   int np = 0;
   int rc = fill_mlp_args(fn, net, &a, &np);
   if (rc) return rc;
-  TRL_REQUIRE(x && acts && dy && grads && ws, "%s: null pointer", fn);
+  TRL_REQUIRE(x && acts && dy && ws && (grads || param_grads), "%s: null pointer", fn);
   TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
+  GradDst gd{};
+  if (param_grads) {
+    gd.nseg = 2 * a.depth;
+    int off = 0;
+    for (int l = 0; l < a.depth; ++l) {
+      TRL_REQUIRE(param_grads[2 * l] && param_grads[2 * l + 1], "%s: null gradient destination of layer %d", fn, l);
+      gd.start[2 * l] = off;
+      gd.dst[2 * l] = param_grads[2 * l];
+      off += a.dims[l + 1] * a.dims[l];
+      gd.start[2 * l + 1] = off;
+      gd.dst[2 * l + 1] = param_grads[2 * l + 1];
+      off += a.dims[l + 1];
+    }
+    gd.start[gd.nseg] = off;
+  }
   for (int l = 0; l + 1 < a.depth; ++l) {
     TRL_REQUIRE(acts[l] != nullptr, "%s: acts[%d] is null", fn, l);
     a.act[l] = (float *)acts[l];
@@ -728,7 +750,7 @@ extern "C" int trl_mlp_bwd(const trl_mlp_desc *net, const float *x, const float 
   hipLaunchKernelGGL(k_mlp_bwd, dim3((unsigned)slabs), dim3(256), 0, st, x, dy, B, a, tps, np, (float *)ws);
   TRL_CHECK_LAUNCH(fn);
   hipLaunchKernelGGL(k_mlp_bwd_reduce, dim3((unsigned)trl_cdiv(np, 16)), dim3(256), 0, st, (const float *)ws, slabs,
-                     np, grads);
+                     np, grads, gd);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
 }

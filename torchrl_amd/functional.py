@@ -344,7 +344,7 @@ def _mlp_desc(weights, biases):
 
 class _Mlp64(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x, *params):
+  def forward(ctx, x, direct, *params):
     import ctypes as C
     x = _f32c(x, 'x')
     weights = [_f32c(p, 'weight') for p in params[0::2]]
@@ -356,6 +356,9 @@ class _Mlp64(torch.autograd.Function):
     with torch.cuda.device(x.device):
       _lib.check(_lib.lib().trl_mlp_fwd(C.byref(desc), x.data_ptr(), B, actp, _lib.stream_ptr(x.device)))
     ctx.depth = len(weights)
+    # direct: the reduce launch writes every parameter's gradient straight into its .grad
+    # (OVERWRITING it) and autograd is handed None -- no AccumulateGrad add per parameter
+    ctx.grad_dst = [p.grad for p in params] if direct else None
     ctx.save_for_backward(x, *weights, *biases, *acts[:-1])
     return acts[-1]
 
@@ -368,14 +371,21 @@ class _Mlp64(torch.autograd.Function):
     dy = dy.contiguous()
     B = x.shape[0]
     desc = _mlp_desc(weights, biases)
-    nparams = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
-    grads = torch.empty(nparams, dtype=torch.float32, device=x.device)
     ws = _linear_ws(x.device, _lib.lib().trl_mlp_bwd_workspace_bytes(C.byref(desc), B))
     actp = (C.c_void_p * 3)(*([t.data_ptr() for t in acts] + [None] * (3 - len(acts))))
+    if ctx.grad_dst is not None:
+      dstp = (C.c_void_p * (2 * D))(*[g.data_ptr() for g in ctx.grad_dst])
+      grads = None
+    else:
+      dstp = None
+      nparams = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
+      grads = torch.empty(nparams, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-      _lib.check(_lib.lib().trl_mlp_bwd(C.byref(desc), x.data_ptr(), actp, dy.data_ptr(), B, grads.data_ptr(),
+      _lib.check(_lib.lib().trl_mlp_bwd(C.byref(desc), x.data_ptr(), actp, dy.data_ptr(), B, _lib.ptr(grads), dstp,
                                         ws.data_ptr(), _lib.stream_ptr(x.device)))
-    out, off = [None], 0
+    if grads is None:
+      return (None, None) + (None,) * (2 * D)
+    out, off = [None, None], 0
     for w, b in zip(weights, biases):
       out.append(grads[off:off + w.numel()].view(w.shape))
       off += w.numel()
@@ -384,10 +394,19 @@ class _Mlp64(torch.autograd.Function):
     return tuple(out)
 
 
-def mlp64(x, weights, biases):
+def mlp64(x, weights, biases, direct_grads=False):
   """Linear -> ReLU -> ... -> Linear (1..3 Linear layers, every width <= 64) as one forward
-  launch and one backward launch (csrc/trl_mlp.hip: k_mlp_fwd / k_mlp_bwd).  x gets no gradient."""
+  launch and one backward launch (csrc/trl_mlp.hip: k_mlp_fwd / k_mlp_bwd).  x gets no gradient.
+
+  direct_grads=True: the backward OVERWRITES each parameter's existing contiguous float32 `.grad`
+  in place instead of returning gradients for autograd to accumulate.  Only valid when the stack
+  is used once per backward pass and its gradients were meant to start from zero (what the
+  controllers' learn() does)."""
   params = []
   for w, b in zip(weights, biases):
     params += [w, b]
-  return _Mlp64.apply(x, *params)
+  if direct_grads:
+    for p in params:
+      if p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32 or p.grad.shape != p.shape:
+        raise ValueError('direct_grads needs an existing contiguous float32 .grad on every parameter')
+  return _Mlp64.apply(x, bool(direct_grads), *params)
