@@ -235,6 +235,16 @@ int64_t trl_mlp_bwd_workspace_bytes(const trl_mlp_desc *net, int64_t B);
 int trl_mlp_bwd(const trl_mlp_desc *net, const float *x, const float *const *acts, const float *dy, int64_t B,
                 float *grads, float *const *param_grads, void *ws, void *stream);
 
+/* The same for a group of G <= 4 independent networks that see the same batch size (the critic
+ * and the actor of an actor-critic; online and target Q-networks) in one launch pair:
+ * xs[g], dys[g]; acts[3 * g + l]; grads[g] or param_grads[6 * g + j]; the workspace is the sum of
+ * the members' trl_mlp_bwd_workspace_bytes(). */
+int trl_mlp_fwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *xs, int64_t B, float *const *acts,
+                      void *stream);
+int trl_mlp_bwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *xs, const float *const *acts,
+                      const float *const *dys, int64_t B, float *const *grads, float *const *param_grads, void *ws,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

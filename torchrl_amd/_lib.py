@@ -70,6 +70,9 @@ PROTOTYPES = {
     'trl_mlp_fwd': (C.c_int, [C.POINTER(MlpDesc), _vp, _i64, C.POINTER(_vp), _vp]),
     'trl_mlp_bwd_workspace_bytes': (_i64, [C.POINTER(MlpDesc), _i64]),
     'trl_mlp_bwd': (C.c_int, [C.POINTER(MlpDesc), _vp, C.POINTER(_vp), _vp, _i64, _vp, C.POINTER(_vp), _vp, _vp]),
+    'trl_mlp_fwd_group': (C.c_int, [C.POINTER(MlpDesc), _i32, C.POINTER(_vp), _i64, C.POINTER(_vp), _vp]),
+    'trl_mlp_bwd_group': (C.c_int, [C.POINTER(MlpDesc), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i64,
+                                    C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
 }
 
 _lib = None

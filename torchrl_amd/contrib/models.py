@@ -102,12 +102,9 @@ class _Mlp(nn.Sequential):
     return x
 
 
-def _whole_net(self, mods, x):
-  """Linear/ReLU alternation of <= 3 Linear layers, all <= 64 wide, input without gradient:
-  one fused forward launch (and one backward launch) for the whole stack; any trailing
-  non-Linear modules (Tanh, Softmax) are applied by torch afterwards."""
-  if x.requires_grad:
-    return None
+def _fusable_stack(mods):
+  """(linear layers, trailing modules) if `mods` is Linear/ReLU alternation of <= 3 Linear layers,
+  all <= 64 wide, followed only by non-Linear, non-ReLU modules (Tanh, Softmax); else None."""
   lin, i = [], 0
   while i < len(mods) and isinstance(mods[i], nn.Linear):
     lin.append(mods[i])
@@ -121,12 +118,50 @@ def _whole_net(self, mods, x):
     return None
   if any(m.bias is None or max(m.in_features, m.out_features) > 64 for m in lin):
     return None
-  direct = getattr(self, 'direct_grads', False) and torch.is_grad_enabled() and \
+  return lin, tail
+
+
+def _direct_ok(stack, lin):
+  return getattr(stack, 'direct_grads', False) and torch.is_grad_enabled() and \
       all(m.weight.grad is not None and m.bias.grad is not None for m in lin)
-  y = _F.mlp64(x, [m.weight for m in lin], [m.bias for m in lin], direct_grads=direct)
+
+
+def _whole_net(self, mods, x):
+  """One fused forward launch (and one backward launch) for the whole stack when it qualifies
+  and its input needs no gradient; trailing modules are applied by torch afterwards."""
+  fs = None if x.requires_grad else _fusable_stack(mods)
+  if fs is None:
+    return None
+  lin, tail = fs
+  y = _F.mlp64(x, [m.weight for m in lin], [m.bias for m in lin], direct_grads=_direct_ok(self, lin))
   for m in tail:
     y = m(y)
   return y
+
+
+def run_stacks(stacks, xs):
+  """Outputs of several _Mlp stacks on same-sized batches.  When every one qualifies for the
+  whole-network kernels they share ONE forward launch and ONE backward launch (the critic and
+  the actor of an actor-critic, online and target Q-networks); otherwise each runs on its own."""
+  x0 = xs[0]
+  ok = (len(stacks) <= 4 and _fused_mlp_enabled() and x0.is_cuda and x0.dim() == 2 and x0.dtype == torch.float32
+        and x0.shape[0] >= _Mlp.FUSED_MIN_BATCH
+        and all(x.shape[0] == x0.shape[0] and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+                for x in xs))
+  fss = [(_fusable_stack(list(s)) if ok and isinstance(s, _Mlp) else None) for s in stacks]
+  if not ok or any(f is None for f in fss):
+    return [s(x) for s, x in zip(stacks, xs)]
+  direct = [_direct_ok(s, f[0]) for s, f in zip(stacks, fss)]
+  if any(direct) and not all(direct):      # mixed: keep it simple, one launch pair each
+    return [s(x) for s, x in zip(stacks, xs)]
+  ys = _F.mlp64_group(xs, [([m.weight for m in lin], [m.bias for m in lin]) for lin, _ in fss],
+                      direct_grads=all(direct))
+  out = []
+  for y, (_, tail) in zip(ys, fss):
+    for m in tail:
+      y = m(y)
+    out.append(y)
+  return out
 
 
 _Mlp._whole_net = _whole_net
@@ -213,7 +248,8 @@ class A2CNet(nn.Module):
     self.actor = _mlp(input_size, sizes, output_size, tail=nn.Softmax(dim=1))
 
   def heads(self, obs):
-    return self.critic(obs), self.actor(obs)
+    value, probs = run_stacks([self.critic, self.actor], [obs, obs])
+    return value, probs
 
   def forward(self, obs):
     value, probs = self.heads(obs)
@@ -236,7 +272,8 @@ class ActorCriticNet(nn.Module):
     self.apply(self.init_weights)   # module order = creation order: critic.*, then actor.*
 
   def heads(self, obs):
-    return self.critic(obs), self.actor(obs), self.log_std
+    value, mean = run_stacks([self.critic, self.actor], [obs, obs])
+    return value, mean, self.log_std
 
   def forward(self, obs):
     value, mean, log_std = self.heads(obs)

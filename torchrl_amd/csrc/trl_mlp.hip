@@ -338,6 +338,15 @@ struct MlpArgs {
   int32_t vec[4];            // vec[l]: rows of width dims[l] are 16 B-loadable (dims % 4 == 0, aligned bases)
 };
 
+constexpr int MAXG = 4;      // networks per grouped launch (blockIdx.y)
+struct MlpGroup {
+  MlpArgs net[MAXG];
+  const float *x[MAXG];
+  const float *dy[MAXG];     // backward only
+  float *ws_part[MAXG];      // backward only: [slabs][nparams[g]]
+  int32_t nparams[MAXG];
+};
+
 constexpr int LDA = 65;      // LDS row stride of every 128 x 64 / 64 x 64 tile
 
 template <bool VEC, int ROWS>
@@ -347,7 +356,9 @@ __device__ __forceinline__ void stage64(float *s, const float *__restrict__ m, i
   r.template store<LDA>(s);
 }
 
-__global__ __launch_bounds__(256) void k_mlp_fwd(const float *__restrict__ x, int64_t B, MlpArgs a) {
+__global__ __launch_bounds__(256) void k_mlp_fwd(int64_t B, MlpGroup grp) {
+  const MlpArgs &a = grp.net[blockIdx.y];       // blockIdx.y: which network of the group
+  const float *__restrict__ x = grp.x[blockIdx.y];
   __shared__ float sA[BM * LDA];     // the current layer's input; overwritten in place by its output
   __shared__ float sW[64 * LDA];     // 50 KB in all: three workgroups per CU, so tiles overlap each other's latency
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -395,9 +406,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float *__restrict__ x, in
 
 // ws_part[slab] holds the slab's parameter-gradient partials, densely: for l = 0..depth-1:
 // dW_l [dims[l+1] * dims[l]] then db_l [dims[l+1]].
-__global__ __launch_bounds__(256) void k_mlp_bwd(const float *__restrict__ x, const float *__restrict__ dy,
-                                                 int64_t B, MlpArgs a, int tiles_per_slab, int nparams,
-                                                 float *__restrict__ ws_part) {
+__global__ __launch_bounds__(256) void k_mlp_bwd(int64_t B, MlpGroup grp, int tiles_per_slab) {
+  const MlpArgs &a = grp.net[blockIdx.y];
+  const float *__restrict__ x = grp.x[blockIdx.y];
+  const float *__restrict__ dy = grp.dy[blockIdx.y];
+  float *__restrict__ ws_part = grp.ws_part[blockIdx.y];
+  const int nparams = grp.nparams[blockIdx.y];
   __shared__ float sG[BM * LDA];     // gradient w.r.t. the current layer's output (masked)
   __shared__ float sAct[BM * LDA];   // the current layer's input activation
   __shared__ float sW[64 * LDA];
@@ -542,8 +556,18 @@ struct GradDst {
   float *dst[6];
 };
 
-__global__ __launch_bounds__(256) void k_mlp_bwd_reduce(const float *__restrict__ ws_part, int nslabs, int nparams,
-                                                        float *__restrict__ grads, GradDst gd) {
+struct ReduceGroup {
+  const float *ws_part[MAXG];
+  float *grads[MAXG];
+  int32_t nparams[MAXG];
+  GradDst gd[MAXG];
+};
+
+__global__ __launch_bounds__(256) void k_mlp_bwd_reduce(int nslabs, ReduceGroup rg) {
+  const float *__restrict__ ws_part = rg.ws_part[blockIdx.y];
+  float *__restrict__ grads = rg.grads[blockIdx.y];
+  const int nparams = rg.nparams[blockIdx.y];
+  const GradDst &gd = rg.gd[blockIdx.y];
   __shared__ float part[16][17];
   const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + e;
@@ -685,72 +709,124 @@ int fill_mlp_args(const char *fn, const trl_mlp_desc *net, MlpArgs *a, int *npar
 inline bool rows16(int width, const void *p) { return width % 4 == 0 && (uintptr_t)p % 16 == 0; }
 }  // namespace
 
-extern "C" int trl_mlp_fwd(const trl_mlp_desc *net, const float *x, int64_t B, float *const *acts, void *stream) {
-  const char *fn = "trl_mlp_fwd";
-  MlpArgs a{};
-  int np = 0;
-  int rc = fill_mlp_args(fn, net, &a, &np);
-  if (rc) return rc;
-  TRL_REQUIRE(x && acts, "%s: null pointer", fn);
+extern "C" int trl_mlp_fwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *xs, int64_t B,
+                                 float *const *acts, void *stream) {
+  const char *fn = "trl_mlp_fwd_group";
+  TRL_REQUIRE(nets && xs && acts, "%s: null pointer", fn);
+  TRL_REQUIRE(G >= 1 && G <= MAXG, "%s: group of %d networks not in [1, %d]", fn, G, MAXG);
   TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
-  for (int l = 0; l < a.depth; ++l) {
-    TRL_REQUIRE(acts[l] != nullptr, "%s: acts[%d] is null", fn, l);
-    a.act[l] = acts[l];
-    a.vec[l] = (l == 0 ? rows16(a.dims[0], x) : rows16(a.dims[l], acts[l - 1])) && rows16(a.dims[l], a.w[l]);
+  MlpGroup grp{};
+  for (int g = 0; g < G; ++g) {
+    MlpArgs &a = grp.net[g];
+    int np = 0;
+    int rc = fill_mlp_args(fn, &nets[g], &a, &np);
+    if (rc) return rc;
+    TRL_REQUIRE(xs[g] != nullptr, "%s: xs[%d] is null", fn, g);
+    grp.x[g] = xs[g];
+    for (int l = 0; l < a.depth; ++l) {
+      float *out = acts[3 * g + l];
+      TRL_REQUIRE(out != nullptr, "%s: acts[%d][%d] is null", fn, g, l);
+      a.act[l] = out;
+      a.vec[l] = (l == 0 ? rows16(a.dims[0], xs[g]) : rows16(a.dims[l], acts[3 * g + l - 1])) &&
+                 rows16(a.dims[l], a.w[l]);
+    }
   }
-  hipLaunchKernelGGL(k_mlp_fwd, dim3((unsigned)trl_cdiv(B, BM)), dim3(256), 0, (hipStream_t)stream, x, B, a);
+  hipLaunchKernelGGL(k_mlp_fwd, dim3((unsigned)trl_cdiv(B, BM), (unsigned)G), dim3(256), 0, (hipStream_t)stream, B,
+                     grp);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
+}
+
+extern "C" int trl_mlp_fwd(const trl_mlp_desc *net, const float *x, int64_t B, float *const *acts, void *stream) {
+  TRL_REQUIRE(net && acts, "trl_mlp_fwd: null pointer");
+  float *a3[3] = {nullptr, nullptr, nullptr};
+  for (int l = 0; l < net->depth && l < 3; ++l) a3[l] = acts[l];
+  return trl_mlp_fwd_group(net, 1, &x, B, a3, stream);
+}
+
+static int64_t mlp_slabs(int64_t B) {
+  const int64_t ntiles = trl_cdiv(B, BM);
+  return ntiles < MAX_SLABS ? ntiles : MAX_SLABS;
 }
 
 extern "C" int64_t trl_mlp_bwd_workspace_bytes(const trl_mlp_desc *net, int64_t B) {
   if (!net || net->depth < 1 || net->depth > 3 || B <= 0) return 0;
   int np = 0;
   for (int l = 0; l < net->depth; ++l) np += net->dims[l + 1] * net->dims[l] + net->dims[l + 1];
+  return mlp_slabs(B) * (int64_t)((np + 3) / 4 * 4) * 4;
+}
+
+extern "C" int trl_mlp_bwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *xs,
+                                 const float *const *acts, const float *const *dys, int64_t B, float *const *grads,
+                                 float *const *param_grads, void *ws, void *stream) {
+  const char *fn = "trl_mlp_bwd_group";
+  TRL_REQUIRE(nets && xs && acts && dys && ws && (grads || param_grads), "%s: null pointer", fn);
+  TRL_REQUIRE(G >= 1 && G <= MAXG, "%s: group of %d networks not in [1, %d]", fn, G, MAXG);
+  TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
   const int64_t ntiles = trl_cdiv(B, BM);
-  const int64_t slabs = ntiles < MAX_SLABS ? ntiles : MAX_SLABS;
-  return slabs * (int64_t)np * 4;
+  const int tps = (int)trl_cdiv(ntiles, mlp_slabs(B));
+  const int slabs = (int)trl_cdiv(ntiles, tps);
+  MlpGroup grp{};
+  ReduceGroup rg{};
+  float *wsp = (float *)ws;
+  int np_max = 0;
+  for (int g = 0; g < G; ++g) {
+    MlpArgs &a = grp.net[g];
+    int np = 0;
+    int rc = fill_mlp_args(fn, &nets[g], &a, &np);
+    if (rc) return rc;
+    TRL_REQUIRE(xs[g] && dys[g], "%s: xs[%d] / dys[%d] is null", fn, g, g);
+    grp.x[g] = xs[g];
+    grp.dy[g] = dys[g];
+    grp.nparams[g] = np;
+    grp.ws_part[g] = wsp;
+    rg.ws_part[g] = wsp;
+    rg.nparams[g] = np;
+    wsp += mlp_slabs(B) * (int64_t)((np + 3) / 4 * 4);
+    np_max = np > np_max ? np : np_max;
+    for (int l = 0; l + 1 < a.depth; ++l) {
+      TRL_REQUIRE(acts[3 * g + l] != nullptr, "%s: acts[%d][%d] is null", fn, g, l);
+      a.act[l] = (float *)acts[3 * g + l];
+    }
+    for (int l = 0; l < a.depth; ++l)
+      a.vec[l] = (l == 0 ? rows16(a.dims[0], xs[g]) : rows16(a.dims[l], acts[3 * g + l - 1])) &&
+                 rows16(a.dims[l], a.w[l]);
+    a.vec[a.depth] = rows16(a.dims[a.depth], dys[g]);
+    GradDst &gd = rg.gd[g];
+    if (param_grads) {
+      gd.nseg = 2 * a.depth;
+      int off = 0;
+      for (int l = 0; l < a.depth; ++l) {
+        float *dw = param_grads[6 * g + 2 * l], *db = param_grads[6 * g + 2 * l + 1];
+        TRL_REQUIRE(dw && db, "%s: null gradient destination of net %d layer %d", fn, g, l);
+        gd.start[2 * l] = off;
+        gd.dst[2 * l] = dw;
+        off += a.dims[l + 1] * a.dims[l];
+        gd.start[2 * l + 1] = off;
+        gd.dst[2 * l + 1] = db;
+        off += a.dims[l + 1];
+      }
+      gd.start[gd.nseg] = off;
+    } else {
+      TRL_REQUIRE(grads[g] != nullptr, "%s: grads[%d] is null", fn, g);
+      rg.grads[g] = grads[g];
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mlp_bwd, dim3((unsigned)slabs, (unsigned)G), dim3(256), 0, st, B, grp, tps);
+  TRL_CHECK_LAUNCH(fn);
+  hipLaunchKernelGGL(k_mlp_bwd_reduce, dim3((unsigned)trl_cdiv(np_max, 16), (unsigned)G), dim3(256), 0, st, slabs, rg);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
 }
 
 extern "C" int trl_mlp_bwd(const trl_mlp_desc *net, const float *x, const float *const *acts, const float *dy,
                            int64_t B, float *grads, float *const *param_grads, void *ws, void *stream) {
-  const char *fn = "trl_mlp_bwd";
-  MlpArgs a{};
-  int np = 0;
-  int rc = fill_mlp_args(fn, net, &a, &np);
-  if (rc) return rc;
-  TRL_REQUIRE(x && acts && dy && ws && (grads || param_grads), "%s: null pointer", fn);
-  TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
-  GradDst gd{};
-  if (param_grads) {
-    gd.nseg = 2 * a.depth;
-    int off = 0;
-    for (int l = 0; l < a.depth; ++l) {
-      TRL_REQUIRE(param_grads[2 * l] && param_grads[2 * l + 1], "%s: null gradient destination of layer %d", fn, l);
-      gd.start[2 * l] = off;
-      gd.dst[2 * l] = param_grads[2 * l];
-      off += a.dims[l + 1] * a.dims[l];
-      gd.start[2 * l + 1] = off;
-      gd.dst[2 * l + 1] = param_grads[2 * l + 1];
-      off += a.dims[l + 1];
-    }
-    gd.start[gd.nseg] = off;
-  }
-  for (int l = 0; l + 1 < a.depth; ++l) {
-    TRL_REQUIRE(acts[l] != nullptr, "%s: acts[%d] is null", fn, l);
-    a.act[l] = (float *)acts[l];
-  }
-  for (int l = 0; l < a.depth; ++l)
-    a.vec[l] = (l == 0 ? rows16(a.dims[0], x) : rows16(a.dims[l], acts[l - 1])) && rows16(a.dims[l], a.w[l]);
-  a.vec[a.depth] = rows16(a.dims[a.depth], dy);
-  const int64_t ntiles = trl_cdiv(B, BM);
-  const int tps = (int)trl_cdiv(ntiles, ntiles < MAX_SLABS ? ntiles : MAX_SLABS);
-  const int slabs = (int)trl_cdiv(ntiles, tps);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_mlp_bwd, dim3((unsigned)slabs), dim3(256), 0, st, x, dy, B, a, tps, np, (float *)ws);
-  TRL_CHECK_LAUNCH(fn);
-  hipLaunchKernelGGL(k_mlp_bwd_reduce, dim3((unsigned)trl_cdiv(np, 16)), dim3(256), 0, st, (const float *)ws, slabs,
-                     np, grads, gd);
-  TRL_CHECK_LAUNCH(fn);
-  return TRL_OK;
+  TRL_REQUIRE(net && acts, "trl_mlp_bwd: null pointer");
+  const float *a3[3] = {nullptr, nullptr, nullptr};
+  for (int l = 0; l + 1 < net->depth && l < 3; ++l) a3[l] = acts[l];
+  float *pg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (param_grads)
+    for (int j = 0; j < 2 * net->depth && j < 6; ++j) pg[j] = param_grads[j];
+  return trl_mlp_bwd_group(net, 1, &x, a3, &dy, B, grads ? &grads : nullptr, param_grads ? pg : nullptr, ws, stream);
 }

@@ -330,83 +330,130 @@ def linear_act(x, weight, bias, relu=False):
   return _LinearAct.apply(x, weight, bias, 1 if relu else 0)
 
 
-def _mlp_desc(weights, biases):
-  import ctypes as C
-  d = _lib.MlpDesc()
+def _fill_desc(d, weights, biases):
   d.depth = len(weights)
   d.dims[0] = weights[0].shape[1]
   for l, (w, b) in enumerate(zip(weights, biases)):
     d.dims[l + 1] = w.shape[0]
     d.w[l] = w.data_ptr()
     d.b[l] = b.data_ptr()
-  return d
 
 
-class _Mlp64(torch.autograd.Function):
+class _Mlp64Group(torch.autograd.Function):
+  """G independent <=64-wide MLPs over batches of the same size: one forward launch, one
+  backward launch + one reduce for the whole group (csrc/trl_mlp.hip)."""
+
   @staticmethod
-  def forward(ctx, x, direct, *params):
+  def forward(ctx, meta, *tensors):
     import ctypes as C
-    x = _f32c(x, 'x')
-    weights = [_f32c(p, 'weight') for p in params[0::2]]
-    biases = [_f32c(p, 'bias') for p in params[1::2]]
-    B = x.shape[0]
-    desc = _mlp_desc(weights, biases)
-    acts = [torch.empty((B, w.shape[0]), dtype=torch.float32, device=x.device) for w in weights]
-    actp = (C.c_void_p * len(acts))(*[t.data_ptr() for t in acts])
-    with torch.cuda.device(x.device):
-      _lib.check(_lib.lib().trl_mlp_fwd(C.byref(desc), x.data_ptr(), B, actp, _lib.stream_ptr(x.device)))
-    ctx.depth = len(weights)
+    direct, depths = meta
+    G = len(depths)
+    xs = [_f32c(t, 'x') for t in tensors[:G]]
+    B = xs[0].shape[0]
+    nets, pos = [], G
+    for D in depths:
+      prm = tensors[pos:pos + 2 * D]
+      nets.append(([_f32c(p, 'weight') for p in prm[0::2]], [_f32c(p, 'bias') for p in prm[1::2]], prm))
+      pos += 2 * D
+    descs = (_lib.MlpDesc * G)()
+    acts, actp = [], (C.c_void_p * (3 * G))()
+    for g, (ws_, bs_, _) in enumerate(nets):
+      if xs[g].shape[0] != B:
+        raise ValueError('mlp64_group: every network must see the same batch size')
+      _fill_desc(descs[g], ws_, bs_)
+      a = [torch.empty((B, w.shape[0]), dtype=torch.float32, device=xs[g].device) for w in ws_]
+      acts.append(a)
+      for l, t in enumerate(a):
+        actp[3 * g + l] = t.data_ptr()
+    xp = (C.c_void_p * G)(*[x.data_ptr() for x in xs])
+    dev = xs[0].device
+    with torch.cuda.device(dev):
+      _lib.check(_lib.lib().trl_mlp_fwd_group(descs, G, xp, B, actp, _lib.stream_ptr(dev)))
+    ctx.depths = depths
     # direct: the reduce launch writes every parameter's gradient straight into its .grad
     # (OVERWRITING it) and autograd is handed None -- no AccumulateGrad add per parameter
-    ctx.grad_dst = [p.grad for p in params] if direct else None
-    ctx.save_for_backward(x, *weights, *biases, *acts[:-1])
-    return acts[-1]
+    ctx.grad_dst = [[p.grad for p in prm] for _, _, prm in nets] if direct else None
+    saved = list(xs)
+    for (ws_, bs_, _), a in zip(nets, acts):
+      saved += list(ws_) + list(bs_) + a[:-1]
+    ctx.save_for_backward(*saved)
+    return tuple(a[-1] for a in acts)
 
   @staticmethod
-  def backward(ctx, dy):
+  def backward(ctx, *dys):
     import ctypes as C
-    D = ctx.depth
+    depths = ctx.depths
+    G = len(depths)
     saved = ctx.saved_tensors
-    x, weights, biases, acts = saved[0], saved[1:1 + D], saved[1 + D:1 + 2 * D], saved[1 + 2 * D:]
-    dy = dy.contiguous()
-    B = x.shape[0]
-    desc = _mlp_desc(weights, biases)
-    ws = _linear_ws(x.device, _lib.lib().trl_mlp_bwd_workspace_bytes(C.byref(desc), B))
-    actp = (C.c_void_p * 3)(*([t.data_ptr() for t in acts] + [None] * (3 - len(acts))))
+    xs, pos = saved[:G], G
+    B, dev = xs[0].shape[0], xs[0].device
+    descs = (_lib.MlpDesc * G)()
+    actp = (C.c_void_p * (3 * G))()
+    nets, nbytes = [], 0
+    for g, D in enumerate(depths):
+      ws_, bs_, a = saved[pos:pos + D], saved[pos + D:pos + 2 * D], saved[pos + 2 * D:pos + 3 * D - 1]
+      pos += 3 * D - 1
+      _fill_desc(descs[g], ws_, bs_)
+      for l, t in enumerate(a):
+        actp[3 * g + l] = t.data_ptr()
+      nets.append((ws_, bs_))
+      nbytes += _lib.lib().trl_mlp_bwd_workspace_bytes(C.byref(descs[g]), B)
+    dyl = []
+    for g, dy in enumerate(dys):
+      if dy is None:      # an unused head: zero gradient
+        dy = torch.zeros((B, nets[g][0][-1].shape[0]), dtype=torch.float32, device=dev)
+      dyl.append(dy.contiguous())
+    xp = (C.c_void_p * G)(*[x.data_ptr() for x in xs])
+    dyp = (C.c_void_p * G)(*[d.data_ptr() for d in dyl])
+    ws = _linear_ws(dev, nbytes)
+    grads, gradp, dstp = None, None, None
     if ctx.grad_dst is not None:
-      dstp = (C.c_void_p * (2 * D))(*[g.data_ptr() for g in ctx.grad_dst])
-      grads = None
+      dstp = (C.c_void_p * (6 * G))()
+      for g, dst in enumerate(ctx.grad_dst):
+        for j, t in enumerate(dst):
+          dstp[6 * g + j] = t.data_ptr()
     else:
-      dstp = None
-      nparams = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
-      grads = torch.empty(nparams, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-      _lib.check(_lib.lib().trl_mlp_bwd(C.byref(desc), x.data_ptr(), actp, dy.data_ptr(), B, _lib.ptr(grads), dstp,
-                                        ws.data_ptr(), _lib.stream_ptr(x.device)))
-    if grads is None:
-      return (None, None) + (None,) * (2 * D)
-    out, off = [None, None], 0
-    for w, b in zip(weights, biases):
-      out.append(grads[off:off + w.numel()].view(w.shape))
-      off += w.numel()
-      out.append(grads[off:off + b.numel()])
-      off += b.numel()
+      grads = [torch.empty(sum(w.numel() + b.numel() for w, b in zip(ws_, bs_)), dtype=torch.float32, device=dev)
+               for ws_, bs_ in nets]
+      gradp = (C.c_void_p * G)(*[t.data_ptr() for t in grads])
+    with torch.cuda.device(dev):
+      _lib.check(_lib.lib().trl_mlp_bwd_group(descs, G, xp, actp, dyp, B, gradp, dstp, ws.data_ptr(),
+                                              _lib.stream_ptr(dev)))
+    out = [None] + [None] * G
+    for g, (ws_, bs_) in enumerate(nets):
+      if grads is None:
+        out += [None] * (2 * len(ws_))
+        continue
+      off = 0
+      for w, b in zip(ws_, bs_):
+        out.append(grads[g][off:off + w.numel()].view(w.shape))
+        off += w.numel()
+        out.append(grads[g][off:off + b.numel()])
+        off += b.numel()
     return tuple(out)
 
 
-def mlp64(x, weights, biases, direct_grads=False):
-  """Linear -> ReLU -> ... -> Linear (1..3 Linear layers, every width <= 64) as one forward
-  launch and one backward launch (csrc/trl_mlp.hip: k_mlp_fwd / k_mlp_bwd).  x gets no gradient.
+def mlp64_group(xs, nets, direct_grads=False):
+  """[(weights, biases), ...] applied to xs[g] (same batch size): Linear -> ReLU -> ... -> Linear,
+  1..3 Linear layers each, every width <= 64, up to 4 networks, as one forward launch and one
+  backward launch (+ reduce).  The inputs get no gradient.  Returns the list of outputs.
 
   direct_grads=True: the backward OVERWRITES each parameter's existing contiguous float32 `.grad`
-  in place instead of returning gradients for autograd to accumulate.  Only valid when the stack
-  is used once per backward pass and its gradients were meant to start from zero (what the
-  controllers' learn() does)."""
-  params = []
-  for w, b in zip(weights, biases):
-    params += [w, b]
+  in place instead of returning gradients for autograd to accumulate.  Only valid when each
+  stack is used once per backward pass and its gradients were meant to start from zero (what
+  the controllers' learn() does)."""
+  tensors, depths = list(xs), []
+  for weights, biases in nets:
+    depths.append(len(weights))
+    for w, b in zip(weights, biases):
+      tensors += [w, b]
   if direct_grads:
-    for p in params:
+    for p in tensors[len(xs):]:
       if p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32 or p.grad.shape != p.shape:
         raise ValueError('direct_grads needs an existing contiguous float32 .grad on every parameter')
-  return _Mlp64.apply(x, bool(direct_grads), *params)
+  return list(_Mlp64Group.apply((bool(direct_grads), tuple(depths)), *tensors))
+
+
+def mlp64(x, weights, biases, direct_grads=False):
+  """One network of mlp64_group."""
+  return mlp64_group([x], [(weights, biases)], direct_grads)[0]
