@@ -64,8 +64,9 @@ def setup_dist(args):
   local = int(os.environ.get('LOCAL_RANK', '0'))
   torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
   local = local % max(1, torch.cuda.device_count())
-  if world > 1:
+  if world > 1 or os.environ.get('TRL_FORCE_GRADSYNC') == '1':
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
     backend = os.environ.get('TRL_BENCH_BACKEND', 'nccl')   # 'gloo' lets a 1-GPU box rehearse N ranks
     if backend == 'nccl':
       dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
@@ -446,7 +447,7 @@ def main():
       ]
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline_ppo(info) if args.workload == 'ppo' else cpu_baseline_offpolicy(info)
-  if world > 1:
+  if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
   if rank == 0:
