@@ -245,6 +245,27 @@ int trl_mlp_bwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *x
                       const float *const *dys, int64_t B, float *const *grads, float *const *param_grads, void *ws,
                       void *stream);
 
+/* ------------------------------------------------------------------ fused PPO learner step (a-2 + a-4)
+ * The device work of PPOController.learn up to the gradients (ppo_controller.py:55-70: forward of
+ * ActorCriticNet's critic and actor, models.py:120-141; the clipped-surrogate / value / entropy
+ * loss; loss.backward()) for networks whose layers are all at most 64 wide, as ONE launch plus a
+ * small fixed-order reduction: a wavefront carries 32 samples from the observation to the
+ * parameter-gradient partials with the activations in registers (csrc/trl_learn.hip).
+ *   critic, actor: depth 2 or 3 (one or two hidden layers, ReLU between), same depth and fan-in;
+ *   critic fan-out 1, actor fan-out A (1 <= A <= 4);  log_std [A];  obs [B, fan-in];
+ *   action, old_logp [B, A];  returns, adv [B].
+ *   losses_out[0..3] = actor, critic, entropy, actor + alpha * critic - beta * entropy.
+ *   critic_grads / actor_grads: 2 * depth destinations (dW_0, db_0, dW_1, ...), e.g. the .grad
+ *   views of a flat gradient buffer, OVERWRITTEN with d loss / d parameter;  dlog_std [A] likewise.
+ * `ws`: trl_ppo_learn_workspace_bytes() bytes of device scratch.  clip_grad_value_ and Adam
+ * (ppo_controller.py:72-74) are trl_adam_step, after the all-reduce when there is one. */
+int64_t trl_ppo_learn_workspace_bytes(const trl_mlp_desc *critic, const trl_mlp_desc *actor, int64_t B);
+int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                        const float *obs, const float *action, const float *returns, const float *old_logp,
+                        const float *adv, int64_t B, int32_t A, double clip, double alpha, double beta,
+                        float *losses_out, float *const *critic_grads, float *const *actor_grads,
+                        float *dlog_std, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

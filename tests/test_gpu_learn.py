@@ -1,0 +1,103 @@
+"""The whole-step PPO kernel (csrc/trl_learn.hip, C ABI trl_ppo_learn_fused) against the oracle's
+torch-CPU restatement of PPOController.learn (oracle/loss_oracle.py: ppo_controller.py:53-80):
+losses, every parameter gradient, and the weights after clip_grad_value_ + Adam.  Tolerances:
+losses 1e-6 relative (the north star's bar; + a 2e-7 absolute floor for terms near 0), gradients
+and weights to fp32 summation-order effects."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle
+from torchrl_amd import functional as F
+from torchrl_amd.contrib.controllers import PPOController
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+# obs size, action size, hidden, batch
+CASES = [(3, 1, (64, 64), 65536), (3, 1, (64, 64), 4097), (4, 2, (64, 64), 9000), (17, 2, (48, 33), 5000),
+         (40, 1, (64, 64), 3000), (64, 2, (64, 64), 2048), (3, 1, (64,), 8192), (5, 4, (64,), 7001),
+         (33, 3, (20,), 300), (3, 1, (64, 64), 256)]
+
+
+def _batch(obs_size, A, B, seed):
+  g = torch.Generator().manual_seed(seed)
+  obs = torch.randn(B, obs_size, generator=g)
+  act = torch.randn(B, A, generator=g)
+  ret = torch.randn(B, 1, generator=g)
+  adv = torch.randn(B, 1, generator=g)
+  return obs, act, ret, adv, g
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B', CASES)
+def test_fused_learn_matches_oracle(obs_size, A, hidden, B):
+  torch.manual_seed(obs_size + 10 * A + B)
+  ctl = PPOController(obs_size, A, lr=3e-4, alpha=0.5, beta=1e-2, clip_ratio=0.2, max_grad_norm=0.05,
+                      device=DEV, hidden=hidden)
+  assert ctl._fused is not None
+  with torch.no_grad():
+    ctl.ac_net.log_std.add_(torch.linspace(-0.3, 0.2, A, device=DEV).view(1, A))
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  ref_opt = torch.optim.Adam(ref.parameters(), lr=3e-4)
+  obs, act, ret, adv, g = _batch(obs_size, A, B, 7 + B)
+  with torch.no_grad():
+    mean = ref.actor(obs)
+    old = torch.distributions.Normal(mean, ref.log_std.exp().expand_as(mean)).log_prob(act)
+    old = old + 0.3 * torch.randn(B, A, generator=g)        # ratios on both sides of the clip range
+  for step in range(1):     # one step deep: Adam turns round-off-sized gradient differences into lr-sized moves
+    exp = loss_oracle.ppo_learn(ref, ref_opt, obs, act, None, None, None, ret, old, adv, clip=0.2, alpha=0.5,
+                                beta=1e-2, max_grad_norm=0.05)
+    exp_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])      # after clip_grad_value_
+    got = ctl.learn(obs.to(DEV), act.to(DEV), None, None, None, ret.to(DEV), old.to(DEV), adv.to(DEV))
+    for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+      e, v = float(exp[k]), float(got[k].cpu())
+      assert abs(v - e) <= 1e-6 * abs(e) + 2e-7, (k, v, e)
+    got_grad = ctl._flat.dense(grad=True).cpu()
+    scale = float(exp_grad.abs().max())
+    np.testing.assert_allclose(got_grad.numpy(), exp_grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
+    exp_w = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    got_w = ctl._flat.dense().cpu()
+    # Adam turns a round-off-sized difference of a near-zero gradient into an lr-sized move
+    assert float((got_w - exp_w).abs().max()) <= 2.5 * 3e-4
+    assert float(((got_w - exp_w).abs() > 1e-5).float().mean()) < 0.02
+
+
+def test_fused_learn_unclipped_gradients_and_general_path(monkeypatch):
+  """Raw gradients (no clamp in the way) of the whole-step kernel vs the layer-by-layer path of the
+  same controller class (autograd over the fused MLP kernels + k_ppo_loss)."""
+  outs = []
+  for mode in ('1', '0'):
+    monkeypatch.setenv('TRL_FUSED_LEARN', mode)
+    torch.manual_seed(11)
+    ctl = PPOController(3, 2, lr=1e-3, alpha=0.5, beta=1e-3, max_grad_norm=1e9, device=DEV, hidden=(64, 64))
+    assert (ctl._fused is not None) == (mode == '1')
+    obs, act, ret, adv, g = _batch(3, 2, 20000, 3)
+    obs, act, ret, adv = (t.to(DEV) for t in (obs, act, ret, adv))
+    with torch.no_grad():
+      _, mean, ls = ctl.ac_net.heads(obs)
+      old = F.normal_log_prob(mean, ls, act) + 0.2 * torch.randn(20000, 2, generator=g).to(DEV)
+    info = ctl.learn(obs, act, None, None, None, ret, old, adv)
+    outs.append((info, ctl._flat.dense(grad=True).clone()))
+  for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+    torch.testing.assert_close(outs[0][0][k], outs[1][0][k], rtol=2e-6, atol=2e-7)
+  scale = float(outs[1][1].abs().max())
+  torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=2e-5 * scale)
+
+
+def test_fused_learn_is_reproducible_and_rejects_bad_shapes():
+  torch.manual_seed(0)
+  ctl = PPOController(3, 1, device=DEV, hidden=(64, 64))
+  obs, act, ret, adv, _ = _batch(3, 1, 30000, 1)
+  obs, act, ret, adv = (t.to(DEV) for t in (obs, act, ret, adv))
+  old = torch.zeros(30000, 1, device=DEV)
+  res = []
+  for _ in range(2):
+    losses = ctl._fused(obs, act, ret, old, adv, 0.2, 0.5, 1e-3)
+    res.append((losses.clone(), ctl._flat.grad.clone()))
+  assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])    # fixed-order sums
+  with pytest.raises(ValueError):
+    ctl._fused(obs, act[:100], ret, old, adv, 0.2, 0.5, 1e-3)
+  assert PPOController(3, 1, device=DEV, hidden=(128, 64))._fused is None              # too wide: general path
+  assert PPOController(3, 3, device=DEV, hidden=(64, 64))._fused is None               # A > 2 with two hidden layers

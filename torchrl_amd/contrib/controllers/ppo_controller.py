@@ -1,5 +1,7 @@
 """PPO controller on the GAE scan and the fused clipped-surrogate kernel
 (reference: ppo_controller.py)."""
+import os
+
 import torch
 
 from ...controllers import Controller
@@ -26,6 +28,11 @@ class PPOController(Controller):
                                  device_state=graph)
     for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
       stack.direct_grads = True
+    self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); TRL_FUSED_LEARN=0 disables
+    if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+      lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
+      if F.FusedPpoLearn.supports(lins[0], lins[1], self.ac_net.log_std):
+        self._fused = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma
@@ -76,6 +83,11 @@ class PPOController(Controller):
 
   def _learn_body(self, obs, action, returns, old_log_probs, advantages):
     """Device work of one learn(): forward, fused loss, backward and (single rank) the update."""
+    if self._fused is not None and self._fused.usable(obs):
+      losses = self._fused(obs, action, returns, old_log_probs, advantages, self.clip_ratio, self.alpha, self.beta)
+      if not self._sync.enabled:
+        self.ac_net_optim.step()
+      return losses[:3]
     value, mean, log_std = self.ac_net.heads(obs)
     loss, parts = F.ppo_loss(mean, log_std, value, action, old_log_probs, advantages, returns,
                              self.clip_ratio, self.alpha, self.beta)

@@ -1,0 +1,719 @@
+// One launch for a whole actor-critic learner step's network work: forward, loss and backward
+// of BOTH small MLPs of ActorCriticNet (torchrl/contrib/models.py:112-147) with the PPO loss of
+// ppo_controller.py:55-68 in between, for one minibatch.  A second small launch sums the
+// per-workgroup gradient partials in a fixed order and writes the gradients and the losses.
+//
+// Why: with <= 64-wide layers a learner step is latency-bound, not HBM- or MFMA-bound.  The
+// layer-by-layer kernels (trl_mlp.hip) hand every activation through LDS behind workgroup
+// barriers and through HBM between forward and backward.  Here a wave owns a strip of 32
+// samples from the observation to the parameter-gradient partials and never meets a barrier:
+//
+//   * "transposed" products: the MFMA computes H^T[n][row] = W[n][k] X^T[k][row], i.e. the
+//     weights are the A operand and the samples sit on the lane axis (row = lane & 31).  The
+//     accumulator layout of v_mfma_f32_32x32x2_f32 (lane: column = lane & 31; register r:
+//     row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) then IS a valid B operand of the next layer's
+//     product once its k index is walked in that same permuted order: register r of lane l
+//     is feature feat(r, l >> 5), and the A operand simply reads W[.][feat(r, l >> 5)].  So
+//     activations (forward) and activation gradients (backward) go from layer to layer in
+//     registers; only the weights are read from LDS.
+//   * weight gradients dW[n][k] = sum_row g[n][row] h[k][row] reduce over the lane axis, so g
+//     and h are transposed through a wave-private LDS tile ([feature][row], stride 33: both the
+//     transposing writes and the operand reads are bank-conflict free) and accumulate in
+//     registers over all strips of the wave.
+//   * the last layer (fan-out <= 4: a value, an action mean per dimension) runs on the VALU:
+//     a dot product per sample, and per-lane partials for its weight gradient.
+//   * bias gradients and last-layer weight gradients are per-lane partial sums over the strips,
+//     reduced across lanes once, at the end.
+//
+// Arithmetic is exact f32 (v_mfma_f32_32x32x2_f32 = k-ordered fma chain); the loss arithmetic
+// is the one of k_ppo_loss (trl_loss.hip), op for op.  Sums over k and over the batch are
+// taken in a different (fixed) order than torch's GEMMs, like any other GEMM kernel.
+#include <stdlib.h>
+
+#include "trl_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LDT = 33;       // row stride of the [feature][row] transpose tiles
+constexpr int LDW = 65;       // row stride of the 64 x 64 weight tile
+constexpr int MAX_WG = 256;   // partial sets per network
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+constexpr float ENT_CONST = 1.41893853320467274178f;
+
+// feature index held by accumulator register r of a lane in half `half` (= lane >> 5)
+__device__ __forceinline__ int feat(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+struct NetArgs {
+  int32_t depth;        // Linear layers: 2 or 3
+  int32_t dims[4];      // dims[0] fan-in; dims[l+1] fan-out of layer l
+  const float *w[3];
+  const float *b[3];
+  int32_t poff[3];      // offset of dW_l in a partial set; db_l follows dW_l
+  int32_t nparams;      // dense parameter count = offset of the extras
+};
+
+// extras of a partial set (after the parameters): [0] sum of (v - ret)^2 (critic) or of
+// min(surr1, surr2) (actor); [1] sum of entropies (actor); [2 + a] dlog_std[a] (actor)
+constexpr int NEXTRA = 8;
+
+struct LearnArgs {
+  NetArgs net[2];       // 0 = critic, 1 = actor
+  const float *obs, *action, *returns, *old_logp, *adv, *log_std;
+  int64_t B;
+  int32_t A;
+  float lo, hi, alpha, beta;
+  float *ws;            // [2][gridDim.x][pstride]
+  int32_t pstride;
+};
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from
+  // moving them across the point where other lanes' data is expected
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc[nb][r] <- vec[nb * 32 + feat(r, half)] : 16 B LDS reads (4 consecutive features per read)
+__device__ __forceinline__ void load_feat_vec(f32x16 (&acc)[2], const float *vec, int half) {
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = *(const float4 *)(vec + nb * 32 + 8 * q + 4 * half);
+      acc[nb][4 * q + 0] = t.x; acc[nb][4 * q + 1] = t.y; acc[nb][4 * q + 2] = t.z; acc[nb][4 * q + 3] = t.w;
+    }
+}
+
+__device__ __forceinline__ void relu2(f32x16 (&h)[2]) {
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[nb][r] = h[nb][r] > 0.f ? h[nb][r] : 0.f;
+}
+
+// tile[(nb * 32 + feat(r, half)) * LDT + row] <- v[nb][r]   (row = lane & 31)
+__device__ __forceinline__ void put_tile(float *tile, const f32x16 (&v)[2], int half, int r32) {
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[(nb * 32 + feat(r, half)) * LDT + r32] = v[nb][r];
+}
+
+// D = depth (2: in -> H -> out, 3: in -> H -> H -> out); KB0 = 32-blocks of the fan-in;
+// NO = padded fan-out of the last layer (actual fan-outs <= NO)
+template <int D, int KB0, int NO>
+__global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
+  constexpr int LDW0 = 32 * KB0 + 1;
+  constexpr int XT = 32 * KB0 * LDT;                 // floats of the x tile
+  constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0);   // per-wave scratch
+  constexpr int WTP = (WT + 3) & ~3;
+  __shared__ __align__(16) float sW0[64 * LDW0];
+  __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];
+  __shared__ __align__(16) float sWL[NO * 64];
+  __shared__ __align__(16) float sB[2 * 64 + 4];     // b0, b1 (padded with zeros), bL
+  __shared__ __align__(16) float sT[4 * WTP];
+  static_assert(4 * WTP >= 64 * 64 + 4 * 64 * 4, "the end-of-kernel reduction re-uses sT");
+
+  const int net = blockIdx.y;
+  const NetArgs &a = P.net[net];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int K0 = a.dims[0], H1 = a.dims[1];
+  const int HL = a.dims[D - 1];      // fan-in of the last layer
+  const int NOr = a.dims[D];         // its actual fan-out
+  const int64_t B = P.B;
+  const int A = P.A;
+
+  // ---- weights, zero-padded, once per workgroup
+  for (int e = tid; e < 64 * LDW0; e += 256) {
+    const int n = e / LDW0, k = e % LDW0;
+    sW0[e] = (n < H1 && k < K0) ? a.w[0][n * K0 + k] : 0.f;
+  }
+  if (D == 3) {
+    const int H2 = a.dims[2];
+    for (int e = tid; e < 64 * LDW; e += 256) {
+      const int n = e / LDW, k = e % LDW;
+      sW1[e] = (n < H2 && k < H1) ? a.w[1][n * H1 + k] : 0.f;
+    }
+  }
+  for (int e = tid; e < NO * 64; e += 256) {
+    const int n = e >> 6, k = e & 63;
+    sWL[e] = (n < NOr && k < HL) ? a.w[D - 1][n * HL + k] : 0.f;
+  }
+  for (int e = tid; e < 2 * 64 + 4; e += 256) {
+    float v = 0.f;
+    if (e < 64) v = e < H1 ? a.b[0][e] : 0.f;
+    else if (e < 128) v = (D == 3 && e - 64 < a.dims[2]) ? a.b[1][e - 64] : 0.f;
+    else v = e - 128 < NOr ? a.b[D - 1][e - 128] : 0.f;
+    sB[e] = v;
+  }
+  float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
+  float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
+  float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T
+  for (int e = lane; e < XT; e += 64) sX[e] = 0.f;   // rows >= K0 stay zero for good
+  __syncthreads();
+
+  // ---- per-wave persistent state
+  f32x16 accW0[2][KB0];
+  f32x16 accW1[2][2];
+  f32x16 db0[2], db1[2];
+  f32x16 dWL[NO][2];
+  float dbL[NO];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+    for (int kb = 0; kb < KB0; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW0[nb][kb][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW1[nb][kb][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { db0[nb][r] = 0.f; db1[nb][r] = 0.f; }
+  }
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    dbL[n] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dWL[n][kb][r] = 0.f;
+  }
+  float s_main = 0.f, s_ent = 0.f;
+  float s_dls[NO];
+  float den[NO], var[NO], logsig[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    s_dls[n] = 0.f;
+    den[n] = var[n] = 1.f; logsig[n] = 0.f;
+    if (net == 1 && n < A) {
+      const float sigma = expf(P.log_std[n]);   // self.log_std.exp()
+      var[n] = sigma * sigma;                   // scale ** 2
+      logsig[n] = logf(sigma);                  // scale.log()
+      den[n] = 2.0f * var[n];
+    }
+  }
+  const float invB = 1.0f / (float)B;
+  const float gmin = -(1.0f / (float)(B * A));   // d loss / d min(surr1, surr2) element
+  const int q64 = 64 / K0, m64 = 64 % K0;
+  const int ksteps0 = (K0 + 1) >> 1;
+
+  const int64_t nstrips = (B + 31) >> 5;
+  for (int64_t strip = (int64_t)blockIdx.x * 4 + wave; strip < nstrips; strip += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = strip << 5;
+    const int64_t row = row0 + r32;
+    const bool valid = row < B;
+    const int64_t rowc = valid ? row : B - 1;
+
+    // ---- x^T of the strip -> sX[k][row] (the strip's rows are contiguous in obs)
+    {
+      const float *base = P.obs + row0 * K0;
+      const int64_t avail = (B - row0) * K0;          // elements before the end of obs
+      const int nelem = 32 * K0;
+      int rr = lane / K0, kk = lane % K0;
+      for (int e = lane; e < nelem; e += 64) {
+        sX[kk * LDT + rr] = e < avail ? base[e] : 0.f;
+        rr += q64; kk += m64;
+        if (kk >= K0) { kk -= K0; ++rr; }
+      }
+    }
+    // ---- per-sample inputs of the loss (both lane halves hold their row's values)
+    float ret = 0.f, ad = 0.f, act[NO], olp[NO];
+    if (net == 0) {
+      ret = P.returns[rowc];
+    } else {
+      ad = P.adv[rowc];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        act[n] = olp[n] = 0.f;
+        if (n < A) { act[n] = P.action[rowc * A + n]; olp[n] = P.old_logp[rowc * A + n]; }
+      }
+    }
+    wave_lds_fence();
+
+    // ---- layer 0: h1^T = relu(W0 x^T + b0)
+    f32x16 h1[2];
+    load_feat_vec(h1, sB, half);
+    for (int s = 0; s < ksteps0; ++s) {
+      const int k = 2 * s + half;
+      const float bv = sX[k * LDT + r32];
+      const float a0 = sW0[r32 * LDW0 + k];
+      const float a1 = sW0[(32 + r32) * LDW0 + k];
+      h1[0] = MFMA(a0, bv, h1[0]);
+      h1[1] = MFMA(a1, bv, h1[1]);
+    }
+    relu2(h1);
+
+    // ---- layer 1 (D == 3): h2^T = relu(W1 h1^T + b1), operands chained in registers
+    f32x16 h2[2];
+    if (D == 3) {
+      load_feat_vec(h2, sB + 64, half);
+      const float *wl = sW1 + r32 * LDW + 4 * half;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int c = kb * 32 + (s & 3) + 8 * (s >> 2);
+          h2[0] = MFMA(wl[c], h1[kb][s], h2[0]);
+          h2[1] = MFMA(wl[32 * LDW + c], h1[kb][s], h2[1]);
+        }
+      relu2(h2);
+    }
+    const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
+
+    // ---- last layer on the VALU: out[n] = WL[n] . hl + bL[n]
+    float out[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      float p = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
+          p = fmaf(w4.x, hl[kb][4 * q + 0], p);
+          p = fmaf(w4.y, hl[kb][4 * q + 1], p);
+          p = fmaf(w4.z, hl[kb][4 * q + 2], p);
+          p = fmaf(w4.w, hl[kb][4 * q + 3], p);
+        }
+      p += __shfl_xor(p, 32, 64);
+      out[n] = p + sB[128 + n];
+    }
+
+    // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
+    float gout[NO];
+    const bool count = valid && half == 0;    // each row's loss terms are summed once
+#pragma unroll
+    for (int n = 0; n < NO; ++n) gout[n] = 0.f;
+    if (net == 0) {
+      const float dv = out[0] - ret;            // mse_loss(values, returns)
+      if (count) s_main += dv * dv;
+      if (valid) gout[0] = P.alpha * ((2.0f * invB) * dv);
+    } else {
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        if (n < A) {
+          const float d = act[n] - out[n];
+          const float sq = d * d;
+          const float lp = ((-sq) / den[n] - logsig[n]) - LOG_SQRT_2PI;   // Normal.log_prob
+          const float ratio = expf(lp - olp[n]);
+          const float s1 = ratio * ad;
+          const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
+          const float s2 = rc * ad;
+          // torch.minimum backward: the smaller side takes the gradient, a tie splits it
+          const float g1 = s1 < s2 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+          const float g2 = s2 < s1 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+          const bool inr = ratio >= P.lo && ratio <= P.hi;   // clamp backward mask
+          const float g_ratio = g1 * ad + (inr ? g2 * ad : 0.f);
+          const float g_lp = g_ratio * ratio;                // exp backward
+          if (count) {
+            s_main += fminf(s1, s2);
+            s_ent += ENT_CONST + logsig[n];
+            s_dls[n] += g_lp * (sq / var[n] - 1.0f);
+          }
+          if (valid) gout[n] = (g_lp / den[n]) * (2.0f * d);
+        }
+      }
+    }
+
+    // ---- last layer backward (VALU): dWL, dbL partials; g = (WL^T gout) * (hl > 0)
+    f32x16 g[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+          const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
+          t[0] = fmaf(w4.x, gout[n], t[0]);
+          t[1] = fmaf(w4.y, gout[n], t[1]);
+          t[2] = fmaf(w4.z, gout[n], t[2]);
+          t[3] = fmaf(w4.w, gout[n], t[3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dWL[n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[n][kb][4 * q + i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = hl[kb][4 * q + i] > 0.f ? t[i] : 0.f;
+      }
+#pragma unroll
+    for (int n = 0; n < NO; ++n)
+      if (half == 0) dbL[n] += gout[n];
+
+    // ---- layer 1 backward (D == 3): dW1 += g h1^T (rows through LDS), g <- (W1^T g) * (h1 > 0)
+    if (D == 3) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) db1[nb][r] += g[nb][r];
+      put_tile(sG, g, half, r32);
+      put_tile(sH, h1, half, r32);
+      wave_lds_fence();
+      const float *ga = sG + r32 * LDT + half, *ha = sH + r32 * LDT + half;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float g0 = ga[2 * s], g1 = ga[32 * LDT + 2 * s];
+        const float x0 = ha[2 * s], x1 = ha[32 * LDT + 2 * s];
+        accW1[0][0] = MFMA(g0, x0, accW1[0][0]);
+        accW1[0][1] = MFMA(g0, x1, accW1[0][1]);
+        accW1[1][0] = MFMA(g1, x0, accW1[1][0]);
+        accW1[1][1] = MFMA(g1, x1, accW1[1][1]);
+      }
+      f32x16 t[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[kb][r] = 0.f;
+      const float *wt = sW1 + (4 * half) * LDW + r32;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int n = nb * 32 + (s & 3) + 8 * (s >> 2);
+          t[0] = MFMA(wt[n * LDW], g[nb][s], t[0]);
+          t[1] = MFMA(wt[n * LDW + 32], g[nb][s], t[1]);
+        }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[kb][r] = h1[kb][r] > 0.f ? t[kb][r] : 0.f;
+    }
+
+    // ---- layer 0 backward: dW0 += g x^T
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) db0[nb][r] += g[nb][r];
+    put_tile(sG, g, half, r32);
+    wave_lds_fence();
+    {
+      const float *ga = sG + r32 * LDT + half, *xa = sX + r32 * LDT + half;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float g0 = ga[2 * s], g1 = ga[32 * LDT + 2 * s];
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) {
+          const float xv = xa[kb * 32 * LDT + 2 * s];
+          accW0[0][kb] = MFMA(g0, xv, accW0[0][kb]);
+          accW0[1][kb] = MFMA(g1, xv, accW0[1][kb]);
+        }
+      }
+    }
+    wave_lds_fence();     // the next strip overwrites sX / sG
+  }
+
+  // =========================================================================== partials out
+  // Everything below runs once per workgroup.  sT is re-used: red[64 * 64] for the weight
+  // tiles, then vsum[4 waves][4 vectors][64] for the per-feature vectors.
+  float *part = P.ws + ((int64_t)net * gridDim.x + blockIdx.x) * P.pstride;
+  float *red = sT;
+  float *vsum = sT + 64 * 64;
+
+  // per-lane partial vectors (db0, db1, dWL[n]) -> per-feature sums over the wave's 32 rows:
+  // transpose through the wave's own tile (sG lies inside sT, so first everyone leaves the loop)
+  __syncthreads();
+  float vec_db0, vec_db1 = 0.f, vec_wl[NO];
+  {
+    put_tile(sG, db0, half, r32);
+    wave_lds_fence();
+    float s = 0.f;
+    for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
+    vec_db0 = s;
+    wave_lds_fence();
+    if (D == 3) {
+      put_tile(sG, db1, half, r32);
+      wave_lds_fence();
+      s = 0.f;
+      for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
+      vec_db1 = s;
+      wave_lds_fence();
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      put_tile(sG, dWL[n], half, r32);
+      wave_lds_fence();
+      s = 0.f;
+      for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
+      vec_wl[n] = s;
+      wave_lds_fence();
+    }
+  }
+  // scalars: wave sums (fixed butterfly order)
+  float sc[2 + 2 * NO];
+  sc[0] = trl_wave_sum(s_main);
+  sc[1] = trl_wave_sum(s_ent);
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    sc[2 + n] = trl_wave_sum(s_dls[n]);
+    sc[2 + NO + n] = trl_wave_sum(dbL[n]);
+  }
+
+  // ---- weight tiles: the four waves' accumulators added in wave order through LDS
+  auto flush_tile = [&](auto &acc, int KBn, int N, int K, int off) {
+    for (int wv = 0; wv < 4; ++wv) {
+      __syncthreads();
+      if (wave == wv) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            if (kb < KBn) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int idx = (nb * 32 + feat(r, half)) * 64 + kb * 32 + r32;
+                red[idx] = wv == 0 ? acc(nb, kb)[r] : red[idx] + acc(nb, kb)[r];
+              }
+            }
+          }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * K; e += 256) part[off + e] = red[(e / K) * 64 + (e % K)];
+  };
+  __syncthreads();     // every wave is done with its own tile region
+  {
+    auto acc0 = [&](int nb, int kb) -> f32x16 & { return accW0[nb][kb < KB0 ? kb : 0]; };
+    flush_tile(acc0, KB0, H1, K0, a.poff[0]);
+  }
+  if (D == 3) {
+    auto acc1 = [&](int nb, int kb) -> f32x16 & { return accW1[nb][kb]; };
+    flush_tile(acc1, 2, a.dims[2], H1, a.poff[1]);
+  }
+  __syncthreads();
+  // ---- per-feature vectors and scalars: [wave][slot][64], summed in wave order
+  vsum[(wave * 4 + 0) * 64 + lane] = vec_db0;
+  vsum[(wave * 4 + 1) * 64 + lane] = vec_db1;
+  __syncthreads();
+  if (tid < 64) {
+    const float s0 = ((vsum[(0 * 4 + 0) * 64 + tid] + vsum[(1 * 4 + 0) * 64 + tid]) + vsum[(2 * 4 + 0) * 64 + tid]) +
+                     vsum[(3 * 4 + 0) * 64 + tid];
+    if (tid < H1) part[a.poff[0] + H1 * K0 + tid] = s0;
+    if (D == 3) {
+      const float s1 = ((vsum[(0 * 4 + 1) * 64 + tid] + vsum[(1 * 4 + 1) * 64 + tid]) + vsum[(2 * 4 + 1) * 64 + tid]) +
+                       vsum[(3 * 4 + 1) * 64 + tid];
+      if (tid < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + tid] = s1;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    __syncthreads();
+    vsum[(wave * 4 + 0) * 64 + lane] = vec_wl[n];
+    __syncthreads();
+    if (tid < HL && n < NOr)
+      part[a.poff[D - 1] + n * HL + tid] =
+          ((vsum[(0 * 4 + 0) * 64 + tid] + vsum[(1 * 4 + 0) * 64 + tid]) + vsum[(2 * 4 + 0) * 64 + tid]) +
+          vsum[(3 * 4 + 0) * 64 + tid];
+  }
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 2 + 2 * NO; ++j) vsum[wave * 16 + j] = sc[j];
+  }
+  __syncthreads();
+  if (tid < 2 + 2 * NO) {
+    const float s = ((vsum[0 * 16 + tid] + vsum[1 * 16 + tid]) + vsum[2 * 16 + tid]) + vsum[3 * 16 + tid];
+    if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
+      if (tid < 2 + A) part[a.nparams + tid] = s;
+    } else {                                  // dbL[n]
+      const int n = tid - 2 - NO;
+      if (n < NOr) part[a.poff[D - 1] + NOr * HL + n] = s;
+    }
+  }
+}
+
+// ---- second launch: sums the partial sets of every workgroup in a fixed order and writes
+// each parameter's gradient to its destination; one extra block finishes the scalars.
+struct GradDst {
+  int32_t nseg;
+  int32_t start[7];
+  float *dst[6];
+};
+
+struct ReduceArgs {
+  const float *ws;
+  int32_t nwg, pstride;
+  int32_t nparams[2];
+  GradDst gd[2];
+  float *losses;      // [4] actor, critic, entropy, total
+  float *dlog_std;    // [A]
+  int64_t B;
+  int32_t A;
+  float alpha, beta, dls_ent;
+};
+
+__global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_blocks) {
+  __shared__ float partS[16][17];
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  if ((int)blockIdx.x < param_blocks) {
+    const int net = blockIdx.y;
+    const int np = R.nparams[net];
+    const float *ws = R.ws + (int64_t)net * R.nwg * R.pstride;
+    const int i = blockIdx.x * 16 + e;
+    float s = 0.f;
+    if (i < np)
+      for (int w = grp; w < R.nwg; w += 16) s += ws[(int64_t)w * R.pstride + i];
+    partS[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && i < np) {
+      float t = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < 16; ++g2) t += partS[g2][e];
+      const GradDst &gd = R.gd[net];
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (j < gd.nseg && i >= gd.start[j] && i < gd.start[j + 1]) gd.dst[j][i - gd.start[j]] = t;
+    }
+    return;
+  }
+  if (blockIdx.y != 0) return;
+  // scalars: slot e < 8: [0] critic sum; [1] actor min-sum; [2] entropy sum; [3 + a] dlog_std[a]
+  float s = 0.f;
+  if (e < 3 + R.A && e < 8) {
+    const int net = e == 0 ? 0 : 1;
+    const int j = e == 0 ? 0 : e - 1;
+    const float *ws = R.ws + (int64_t)net * R.nwg * R.pstride + R.nparams[net] + j;
+    for (int w = grp; w < R.nwg; w += 16) s += ws[(int64_t)w * R.pstride];
+  }
+  partS[grp][e] = s;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) t += partS[g2][e];
+    partS[0][e] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float invBA = 1.0f / (float)(R.B * R.A);
+    const float actor = -(partS[0][1] * invBA);
+    const float critic = partS[0][0] * (1.0f / (float)R.B);
+    const float ent = partS[0][2] * invBA;
+    R.losses[0] = actor;
+    R.losses[1] = critic;
+    R.losses[2] = ent;
+    R.losses[3] = (actor + R.alpha * critic) - R.beta * ent;
+  }
+  if ((int)threadIdx.x < R.A && threadIdx.x < 5) R.dlog_std[threadIdx.x] = partS[0][3 + threadIdx.x] + R.dls_ent;
+}
+
+int fill_net(const char *fn, const trl_mlp_desc *d, int out_max, NetArgs *a) {
+  TRL_REQUIRE(d != nullptr, "%s: null network description", fn);
+  TRL_REQUIRE(d->depth == 2 || d->depth == 3, "%s: depth %d not in {2, 3}", fn, d->depth);
+  a->depth = d->depth;
+  int off = 0;
+  for (int l = 0; l <= d->depth; ++l) {
+    const int lim = l == d->depth ? out_max : 64;
+    TRL_REQUIRE(d->dims[l] >= 1 && d->dims[l] <= lim, "%s: dims[%d]=%d must be in [1, %d]", fn, l, d->dims[l], lim);
+    a->dims[l] = d->dims[l];
+  }
+  for (int l = 0; l < d->depth; ++l) {
+    TRL_REQUIRE(d->w[l] && d->b[l], "%s: null weight/bias of layer %d", fn, l);
+    a->w[l] = d->w[l];
+    a->b[l] = d->b[l];
+    a->poff[l] = off;
+    off += d->dims[l + 1] * d->dims[l] + d->dims[l + 1];
+  }
+  a->nparams = off;
+  return TRL_OK;
+}
+
+int fill_dst(const char *fn, const NetArgs &a, float *const *pg, GradDst *gd) {
+  gd->nseg = 2 * a.depth;
+  int off = 0;
+  for (int l = 0; l < a.depth; ++l) {
+    TRL_REQUIRE(pg[2 * l] && pg[2 * l + 1], "%s: null gradient destination of layer %d", fn, l);
+    gd->start[2 * l] = off;
+    gd->dst[2 * l] = pg[2 * l];
+    off += a.dims[l + 1] * a.dims[l];
+    gd->start[2 * l + 1] = off;
+    gd->dst[2 * l + 1] = pg[2 * l + 1];
+    off += a.dims[l + 1];
+  }
+  gd->start[gd->nseg] = off;
+  return TRL_OK;
+}
+
+inline int learn_wgs(int64_t B) {
+  // one workgroup per CU over both networks: 128 per network, fewer when the batch is small
+  const int64_t need = trl_cdiv(trl_cdiv(B, 32), 4);
+  return (int)(need < 128 ? need : 128);
+}
+
+inline int pstride_of(int np0, int np1) {
+  const int m = (np0 > np1 ? np0 : np1) + NEXTRA;
+  return (m + 3) & ~3;
+}
+
+}  // namespace
+
+extern "C" int64_t trl_ppo_learn_workspace_bytes(const trl_mlp_desc *critic, const trl_mlp_desc *actor, int64_t B) {
+  if (!critic || !actor || B <= 0) return 0;
+  int np[2] = {0, 0};
+  const trl_mlp_desc *d[2] = {critic, actor};
+  for (int g = 0; g < 2; ++g) {
+    if (d[g]->depth < 1 || d[g]->depth > 3) return 0;
+    for (int l = 0; l < d[g]->depth; ++l) np[g] += d[g]->dims[l + 1] * d[g]->dims[l] + d[g]->dims[l + 1];
+  }
+  return 2ll * MAX_WG * pstride_of(np[0], np[1]) * 4;
+}
+
+extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                   const float *obs, const float *action, const float *returns,
+                                   const float *old_logp, const float *adv, int64_t B, int32_t A, double clip,
+                                   double alpha, double beta, float *losses_out, float *const *critic_grads,
+                                   float *const *actor_grads, float *dlog_std, void *ws, void *stream) {
+  const char *fn = "trl_ppo_learn_fused";
+  TRL_REQUIRE(log_std && obs && action && returns && old_logp && adv && losses_out && critic_grads && actor_grads &&
+                  dlog_std && ws,
+              "%s: null pointer", fn);
+  TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
+  TRL_REQUIRE(A >= 1 && A <= 4, "%s: action size %d not in [1, 4]", fn, A);
+  TRL_REQUIRE(critic && actor, "%s: null network description", fn);
+  TRL_REQUIRE(A <= 2 || actor->depth == 2, "%s: two hidden layers take an action size of at most 2 (got %d)", fn, A);
+  LearnArgs P{};
+  int rc = fill_net(fn, critic, 1, &P.net[0]);
+  if (rc) return rc;
+  rc = fill_net(fn, actor, A, &P.net[1]);
+  if (rc) return rc;
+  TRL_REQUIRE(P.net[1].dims[actor->depth] == A, "%s: the actor's fan-out %d is not the action size %d", fn,
+              P.net[1].dims[actor->depth], A);
+  TRL_REQUIRE(critic->depth == actor->depth && critic->dims[0] == actor->dims[0],
+              "%s: critic and actor must have the same depth and observation size", fn);
+  P.obs = obs; P.action = action; P.returns = returns; P.old_logp = old_logp; P.adv = adv; P.log_std = log_std;
+  P.B = B; P.A = A;
+  P.lo = (float)(1.0 - clip); P.hi = (float)(1.0 + clip); P.alpha = (float)alpha; P.beta = (float)beta;
+  P.ws = (float *)ws;
+  P.pstride = pstride_of(P.net[0].nparams, P.net[1].nparams);
+  const int nwg = learn_wgs(B);
+  ReduceArgs R{};
+  R.ws = (const float *)ws; R.nwg = nwg; R.pstride = P.pstride;
+  R.nparams[0] = P.net[0].nparams; R.nparams[1] = P.net[1].nparams;
+  rc = fill_dst(fn, P.net[0], critic_grads, &R.gd[0]);
+  if (rc) return rc;
+  rc = fill_dst(fn, P.net[1], actor_grads, &R.gd[1]);
+  if (rc) return rc;
+  R.losses = losses_out; R.dlog_std = dlog_std; R.B = B; R.A = A;
+  R.alpha = P.alpha; R.beta = P.beta; R.dls_ent = (float)(-beta / (double)A);
+
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)nwg, 2), block(256);
+  const int D = critic->depth, KB0 = critic->dims[0] <= 32 ? 1 : 2, NOv = A <= 1 ? 1 : (A <= 2 ? 2 : 4);
+#define TRL_LEARN_CASE(d, kb, no) \
+  if (D == d && KB0 == kb && NOv == no) hipLaunchKernelGGL((k_ac_learn<d, kb, no>), grid, block, 0, st, P);
+  TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
+  TRL_LEARN_CASE(2, 2, 1) TRL_LEARN_CASE(2, 2, 2) TRL_LEARN_CASE(2, 2, 4)
+  TRL_LEARN_CASE(3, 1, 1) TRL_LEARN_CASE(3, 1, 2)
+  TRL_LEARN_CASE(3, 2, 1) TRL_LEARN_CASE(3, 2, 2)
+#undef TRL_LEARN_CASE
+  TRL_CHECK_LAUNCH(fn);
+  const int np_max = R.nparams[0] > R.nparams[1] ? R.nparams[0] : R.nparams[1];
+  const int pblocks = (int)trl_cdiv(np_max, 16);
+  hipLaunchKernelGGL(k_learn_reduce, dim3((unsigned)pblocks + 1, 2), dim3(256), 0, st, R, pblocks);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}

@@ -457,3 +457,93 @@ def mlp64_group(xs, nets, direct_grads=False):
 def mlp64(x, weights, biases, direct_grads=False):
   """One network of mlp64_group."""
   return mlp64_group([x], [(weights, biases)], direct_grads)[0]
+
+
+# ------------------------------------------------------------------------------ fused PPO learner step
+class FusedPpoLearn:
+  """forward + PPO loss + backward of an ActorCriticNet whose stacks are at most 64 wide, as one
+  launch (+ a small reduce): csrc/trl_learn.hip, C ABI trl_ppo_learn_fused.
+
+  Built once per controller from the stacks' Linear modules (whose parameters and .grad views live
+  in flat buffers, optim.FlatParams): the ctypes argument block is prepared here, so a call costs
+  five data_ptr() reads and one foreign call.  Every parameter's .grad is OVERWRITTEN with
+  d loss / d parameter (no zero_grad needed); returns the [4] loss tensor
+  (actor, critic, entropy, total)."""
+
+  MIN_BATCH = 256
+
+  @staticmethod
+  def supports(critic_lin, actor_lin, log_std):
+    if len(critic_lin) != len(actor_lin) or len(critic_lin) not in (2, 3):
+      return False
+    A = actor_lin[-1].out_features
+    if critic_lin[-1].out_features != 1 or log_std.numel() != A or A > (2 if len(critic_lin) == 3 else 4):
+      return False
+    if critic_lin[0].in_features != actor_lin[0].in_features:
+      return False
+    for lin in (critic_lin, actor_lin):
+      for i, m in enumerate(lin):
+        if m.bias is None or m.in_features > 64 or (i + 1 < len(lin) and m.out_features > 64):
+          return False
+        if m.weight.dtype != torch.float32 or not m.weight.is_cuda:
+          return False
+    return True
+
+  def __init__(self, critic_lin, actor_lin, log_std):
+    import ctypes as C
+    self._C = C
+    self.critic_lin, self.actor_lin, self.log_std = list(critic_lin), list(actor_lin), log_std
+    self.A = actor_lin[-1].out_features
+    self.K0 = critic_lin[0].in_features
+    self.device = log_std.device
+    self._key = None
+    self._bind()
+
+  def _ptr_key(self):
+    return (self.critic_lin[0].weight.data_ptr(), self.actor_lin[-1].bias.data_ptr(), self.log_std.data_ptr(),
+            self.critic_lin[0].weight.grad.data_ptr() if self.critic_lin[0].weight.grad is not None else 0,
+            self.log_std.grad.data_ptr() if self.log_std.grad is not None else 0)
+
+  def _bind(self):
+    C = self._C
+    self.descs = (_lib.MlpDesc * 2)()
+    self.gradp = ((C.c_void_p * 6)(), (C.c_void_p * 6)())
+    for g, lin in enumerate((self.critic_lin, self.actor_lin)):
+      ws_ = [m.weight for m in lin]
+      bs_ = [m.bias for m in lin]
+      for t in ws_ + bs_ + [self.log_std]:
+        if t.grad is None or not t.grad.is_contiguous() or not t.is_contiguous():
+          raise ValueError('FusedPpoLearn needs contiguous parameters with an existing contiguous .grad')
+      _fill_desc(self.descs[g], ws_, bs_)
+      for l, (w, b) in enumerate(zip(ws_, bs_)):
+        self.gradp[g][2 * l] = w.grad.data_ptr()
+        self.gradp[g][2 * l + 1] = b.grad.data_ptr()
+    self._key = self._ptr_key()
+
+  def usable(self, obs):
+    return obs.is_cuda and obs.dim() == 2 and obs.dtype == torch.float32 and obs.shape[0] >= self.MIN_BATCH \
+        and obs.shape[1] == self.K0
+
+  def __call__(self, obs, action, returns, old_logp, adv, clip, alpha, beta):
+    C = self._C
+    B = obs.shape[0]
+    obs = _f32c(obs, 'obs')
+    action = _f32c(action, 'action')
+    returns = _f32c(returns, 'returns')
+    old_logp = _f32c(old_logp, 'old_log_probs')
+    adv = _f32c(adv, 'advantages')
+    if action.numel() != B * self.A or old_logp.numel() != B * self.A or returns.numel() != B or adv.numel() != B:
+      raise ValueError('ppo_learn_fused: inconsistent shapes')
+    if self._ptr_key() != self._key:     # parameters or gradients were re-homed
+      self._bind()
+    dev = obs.device
+    lib = _lib.lib()
+    ws = _linear_ws(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_ppo_learn_fused(
+          C.byref(self.descs[0]), C.byref(self.descs[1]), self.log_std.data_ptr(), obs.data_ptr(),
+          action.data_ptr(), returns.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), B, self.A, float(clip),
+          float(alpha), float(beta), losses.data_ptr(), self.gradp[0], self.gradp[1],
+          self.log_std.grad.data_ptr(), ws.data_ptr(), _lib.stream_ptr(dev)))
+    return losses
