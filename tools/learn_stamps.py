@@ -1,0 +1,40 @@
+"""In-kernel timeline of k_ac_learn from a DIAGNOSTIC build (TRL_LEARN_STAMP=1 python -m
+torchrl_amd._build --force): per wave, shader-clock and 100 MHz stamps at entry, after the weight
+staging, after the strip loop and at the end.  Prints the medians and the in-kernel clock."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchrl_amd import functional as F  # noqa: E402
+from torchrl_amd.contrib.controllers import PPOController  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+dev = torch.device('cuda', 0)
+torch.manual_seed(0)
+ctl = PPOController(3, 1, device=dev, hidden=(64, 64))
+obs, act = torch.randn(B, 3, device=dev), torch.randn(B, 1, device=dev)
+ret, adv, old = torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev) - 1
+f = ctl._fused
+for _ in range(3000):          # >= 2 s of back-to-back launches
+  f(obs, act, ret, old, adv, 0.2, 0.5, 1e-3)
+torch.cuda.synchronize()
+ws = F._lin_ws[0]
+np_c, np_a = 4481, 4481
+pstride = (max(np_c, np_a) + 8 + 3) // 4 * 4
+nwg = min(128, (B + 127) // 128)
+raw = ws[2 * 128 * pstride * 4:2 * 128 * pstride * 4 + 2 * nwg * 4 * 64].cpu().numpy().view(np.uint64)
+st = raw.reshape(2 * nwg * 4, 8).astype(np.float64)
+clk, rt = st[:, 0::2], st[:, 1::2]
+for i, name in enumerate(('staging', 'strip loop', 'partials out')):
+  dc, dr = clk[:, i + 1] - clk[:, i], rt[:, i + 1] - rt[:, i]
+  print('%-13s median %8.0f shader cycles  %6.2f us' % (name, np.median(dc), np.median(dr) / 100.0))
+dc, dr = clk[:, 3] - clk[:, 0], rt[:, 3] - rt[:, 0]
+print('whole wave    median %8.0f shader cycles  %6.2f us; clock %.2f GHz' % (np.median(dc), np.median(dr) / 100.0,
+                                                                             np.median(dc / dr) * 0.1))
+print('first entry -> last exit over all waves: %.2f us' % ((rt[:, 3].max() - rt[:, 0].min()) / 100.0))
+print('entry spread: %.2f us' % ((rt[:, 0].max() - rt[:, 0].min()) / 100.0))
+dc, dr = clk[:, 2] - clk[:, 1], rt[:, 2] - rt[:, 1]
+print('loop clock %.2f GHz' % (np.median(dc / dr) * 0.1))

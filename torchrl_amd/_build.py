@@ -52,7 +52,8 @@ def build_library(force=False, verbose=True):
       cmd = [shutil.which('g++') or 'g++', '-O3', '-std=c++17', '-fPIC', '-Wall', '-I',
              os.path.join(ROOT, 'include'), '-c', os.path.join(CSRC, s), '-o', obj]
     else:
-      cmd = [hipcc] + FLAGS + ['-x', 'hip', '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-c',
+      extra = ['-DTRL_LEARN_STAMP'] if os.environ.get('TRL_LEARN_STAMP') == '1' else []   # diagnostic build
+      cmd = [hipcc] + FLAGS + extra + ['-x', 'hip', '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-c',
                                os.path.join(CSRC, s), '-o', obj]
     if verbose:
       print(' '.join(cmd), flush=True)

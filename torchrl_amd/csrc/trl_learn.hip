@@ -17,9 +17,13 @@
 //     activations (forward) and activation gradients (backward) go from layer to layer in
 //     registers; only the weights are read from LDS.
 //   * weight gradients dW[n][k] = sum_row g[n][row] h[k][row] reduce over the lane axis, so g
-//     and h are transposed through a wave-private LDS tile ([feature][row], stride 33: both the
-//     transposing writes and the operand reads are bank-conflict free) and accumulate in
+//     and h are transposed through a wave-private LDS tile ([feature][row], stride 36: the
+//     transposing writes and the 16 B operand reads are bank-conflict free) and accumulate in
 //     registers over all strips of the wave.
+//   * every MFMA operand that comes from LDS is fetched four k-steps at a time with one
+//     ds_read_b128 (the k order of a product is free, so it is chosen to make a lane's four
+//     consecutive steps contiguous), one group ahead of the MFMAs that consume it: with one
+//     wave per SIMD nothing else hides the LDS latency.
 //   * the last layer (fan-out <= 4: a value, an action mean per dimension) runs on the VALU:
 //     a dot product per sample, and per-lane partials for its weight gradient.
 //   * bias gradients and last-layer weight gradients are per-lane partial sums over the strips,
@@ -36,8 +40,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int LDT = 33;       // row stride of the [feature][row] transpose tiles
-constexpr int LDW = 65;       // row stride of the 64 x 64 weight tile
+constexpr int LDT = 36;       // row stride of the [feature][row] transpose tiles (16 B rows: ds_read_b128 operands)
+constexpr int LDW = 68;       // row stride of the 64 x 64 weight tiles
 constexpr int MAX_WG = 256;   // partial sets per network
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float ENT_CONST = 1.41893853320467274178f;
@@ -70,6 +74,22 @@ struct LearnArgs {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Diagnostic build only (-DTRL_LEARN_STAMP, tools/learn_stamps.py): shader-clock and 100 MHz
+// real-time stamps per wave at four points, written to the unused upper half of the workspace.
+#ifdef TRL_LEARN_STAMP
+#define STAMP(i)                                                                                        \
+  do {                                                                                                  \
+    if (lane == 0) {                                                                                    \
+      unsigned long long *sp = (unsigned long long *)(P.ws + 2ll * 128 * P.pstride) +                   \
+                               (((int64_t)net * gridDim.x + blockIdx.x) * 4 + wave) * 8;                \
+      sp[2 * (i)] = __builtin_amdgcn_s_memtime();                                                       \
+      sp[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                                               \
+    }                                                                                                   \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from
   // moving them across the point where other lanes' data is expected
@@ -93,8 +113,17 @@ __device__ __forceinline__ void relu2(f32x16 (&h)[2]) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h[nb][r] = h[nb][r] > 0.f ? h[nb][r] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      float y;
+      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(h[nb][r]));   // one instruction (fmaxf adds a canonicalize)
+      h[nb][r] = y;
+    }
 }
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)p; }
+__device__ __forceinline__ float f4(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+// keeps LDS reads issued above this point above it (the operand prefetch)
+__device__ __forceinline__ void issue_fence() { asm volatile("" ::: "memory"); }
 
 // tile[(nb * 32 + feat(r, half)) * LDT + row] <- v[nb][r]   (row = lane & 31)
 __device__ __forceinline__ void put_tile(float *tile, const f32x16 (&v)[2], int half, int r32) {
@@ -113,11 +142,13 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0);   // per-wave scratch
   constexpr int WTP = (WT + 3) & ~3;
   __shared__ __align__(16) float sW0[64 * LDW0];
-  __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];
+  __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];    // W1[n][k]
+  __shared__ __align__(16) float sW1T[D == 3 ? 64 * LDW : 4];   // W1^T: [k][n], the backward's A operand
   __shared__ __align__(16) float sWL[NO * 64];
   __shared__ __align__(16) float sB[2 * 64 + 4];     // b0, b1 (padded with zeros), bL
   __shared__ __align__(16) float sT[4 * WTP];
-  static_assert(4 * WTP >= 64 * 64 + 4 * 64 * 4, "the end-of-kernel reduction re-uses sT");
+  static_assert(WTP >= 64 * 32 * KB0 && (D == 2 || WTP >= 64 * 64) && 4 * WTP >= 4 * 8 * 64 + 64,
+                "the end-of-kernel reduction re-uses the per-wave scratch");
 
   const int net = blockIdx.y;
   const NetArgs &a = P.net[net];
@@ -128,16 +159,35 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int64_t B = P.B;
   const int A = P.A;
 
-  // ---- weights, zero-padded, once per workgroup
-  for (int e = tid; e < 64 * LDW0; e += 256) {
-    const int n = e / LDW0, k = e % LDW0;
-    sW0[e] = (n < H1 && k < K0) ? a.w[0][n * K0 + k] : 0.f;
+  STAMP(0);
+  // ---- weights, zero-padded, once per workgroup.  Loads first, stores after: every load of a
+  // tile is in flight at once (a load -> store loop would pay the L2 latency per iteration)
+  {
+    constexpr int N0 = (64 * LDW0 + 255) / 256;
+    float v[N0];
+#pragma unroll
+    for (int i = 0; i < N0; ++i) {
+      const int e = tid + 256 * i, n = e / LDW0, k = e % LDW0;
+      v[i] = (n < H1 && k < K0 && e < 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < N0; ++i)
+      if (tid + 256 * i < 64 * LDW0) sW0[tid + 256 * i] = v[i];
   }
   if (D == 3) {
     const int H2 = a.dims[2];
-    for (int e = tid; e < 64 * LDW; e += 256) {
-      const int n = e / LDW, k = e % LDW;
-      sW1[e] = (n < H2 && k < H1) ? a.w[1][n * H1 + k] : 0.f;
+    constexpr int N1 = 64 * 64 / 256;
+    float v[N1];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
+      v[i] = (n < H2 && k < H1) ? a.w[1][n * H1 + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
+      sW1[n * LDW + k] = v[i];
+      sW1T[k * LDW + n] = v[i];
     }
   }
   for (int e = tid; e < NO * 64; e += 256) {
@@ -156,6 +206,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;   // rows >= K0 stay zero for good
   __syncthreads();
+  STAMP(1);
 
   // ---- per-wave persistent state
   f32x16 accW0[2][KB0];
@@ -203,18 +254,66 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int q64 = 64 / K0, m64 = 64 % K0;
   const int ksteps0 = (K0 + 1) >> 1;
 
-  const int64_t nstrips = (B + 31) >> 5;
-  for (int64_t strip = (int64_t)blockIdx.x * 4 + wave; strip < nstrips; strip += (int64_t)gridDim.x * 4) {
+  // ---- inputs of a strip are fetched one strip ahead, into registers (nothing else would
+  // hide the HBM latency): XPF observation elements per lane (fan-in <= 12; wider observations
+  // are read in place) and the per-sample loss inputs (both lane halves hold their row's values)
+  constexpr int XPF = 6;
+  const bool xpf = 32 * K0 <= 64 * XPF;
+  int xoff[XPF];
+  {
+    int rr = lane / K0, kk = lane % K0;
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) {
+      xoff[j] = kk * LDT + rr;
+      rr += q64; kk += m64;
+      if (kk >= K0) { kk -= K0; ++rr; }
+    }
+  }
+  float xr[XPF], p_ret = 0.f, p_ad = 0.f, p_act[NO], p_olp[NO];
+#pragma unroll
+  for (int j = 0; j < XPF; ++j) xr[j] = 0.f;
+#pragma unroll
+  for (int n = 0; n < NO; ++n) p_act[n] = p_olp[n] = 0.f;
+  const int nelem = 32 * K0;
+  auto fetch = [&](int64_t strip) {
     const int64_t row0 = strip << 5;
     const int64_t row = row0 + r32;
-    const bool valid = row < B;
-    const int64_t rowc = valid ? row : B - 1;
-
-    // ---- x^T of the strip -> sX[k][row] (the strip's rows are contiguous in obs)
-    {
+    const int64_t rowc = row < B ? row : B - 1;
+    if (xpf) {
       const float *base = P.obs + row0 * K0;
       const int64_t avail = (B - row0) * K0;          // elements before the end of obs
-      const int nelem = 32 * K0;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) {
+        const int e = lane + 64 * j;
+        xr[j] = (e < nelem && e < avail) ? base[e] : 0.f;
+      }
+    }
+    if (net == 0) {
+      p_ret = P.returns[rowc];
+    } else {
+      p_ad = P.adv[rowc];
+#pragma unroll
+      for (int n = 0; n < NO; ++n)
+        if (n < A) { p_act[n] = P.action[rowc * A + n]; p_olp[n] = P.old_logp[rowc * A + n]; }
+    }
+  };
+
+  const int64_t nstrips = (B + 31) >> 5;
+  const int64_t sstride = (int64_t)gridDim.x * 4;
+  int64_t strip = (int64_t)blockIdx.x * 4 + wave;
+  if (strip < nstrips) fetch(strip);
+  for (; strip < nstrips; strip += sstride) {
+    const int64_t row0 = strip << 5;
+    const bool valid = row0 + r32 < B;
+
+    // ---- x^T of the strip -> sX[k][row] (the strip's rows are contiguous in obs)
+    if (xpf) {
+#pragma unroll
+      for (int j = 0; j < XPF; ++j)
+        if (lane + 64 * j < nelem) sX[xoff[j]] = xr[j];
+    } else {
+      const float *base = P.obs + row0 * K0;
+      const int64_t avail = (B - row0) * K0;
       int rr = lane / K0, kk = lane % K0;
       for (int e = lane; e < nelem; e += 64) {
         sX[kk * LDT + rr] = e < avail ? base[e] : 0.f;
@@ -222,18 +321,11 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
         if (kk >= K0) { kk -= K0; ++rr; }
       }
     }
-    // ---- per-sample inputs of the loss (both lane halves hold their row's values)
-    float ret = 0.f, ad = 0.f, act[NO], olp[NO];
-    if (net == 0) {
-      ret = P.returns[rowc];
-    } else {
-      ad = P.adv[rowc];
+    const float ret = p_ret, ad = p_ad;
+    float act[NO], olp[NO];
 #pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        act[n] = olp[n] = 0.f;
-        if (n < A) { act[n] = P.action[rowc * A + n]; olp[n] = P.old_logp[rowc * A + n]; }
-      }
-    }
+    for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
+    if (strip + sstride < nstrips) fetch(strip + sstride);
     wave_lds_fence();
 
     // ---- layer 0: h1^T = relu(W0 x^T + b0)
@@ -253,15 +345,26 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     f32x16 h2[2];
     if (D == 3) {
       load_feat_vec(h2, sB + 64, half);
+      // group gq = (kb, q): steps s = 4q .. 4q+3 of k-block kb, i.e. features kb*32 + 8q + 4half + i
       const float *wl = sW1 + r32 * LDW + 4 * half;
+      float4 a0 = ld4(wl), a1 = ld4(wl + 32 * LDW);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const int c = kb * 32 + (s & 3) + 8 * (s >> 2);
-          h2[0] = MFMA(wl[c], h1[kb][s], h2[0]);
-          h2[1] = MFMA(wl[32 * LDW + c], h1[kb][s], h2[1]);
+      for (int gq = 0; gq < 8; ++gq) {
+        const int kb = gq >> 2, q = gq & 3;
+        float4 n0 = a0, n1 = a1;
+        if (gq + 1 < 8) {
+          const int c = ((gq + 1) >> 2) * 32 + 8 * ((gq + 1) & 3);
+          n0 = ld4(wl + c);
+          n1 = ld4(wl + 32 * LDW + c);
         }
+        issue_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          h2[0] = MFMA(f4(a0, i), h1[kb][4 * q + i], h2[0]);
+          h2[1] = MFMA(f4(a1, i), h1[kb][4 * q + i], h2[1]);
+        }
+        a0 = n0; a1 = n1;
+      }
       relu2(h2);
     }
     const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
@@ -354,30 +457,55 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       put_tile(sG, g, half, r32);
       put_tile(sH, h1, half, r32);
       wave_lds_fence();
-      const float *ga = sG + r32 * LDT + half, *ha = sH + r32 * LDT + half;
+      // rows in the order (j, half, i) -> row 8j + 4half + i: a lane's four steps are one 16 B read
+      const float *ga = sG + r32 * LDT + 4 * half, *ha = sH + r32 * LDT + 4 * half;
+      {
+        float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), x0 = ld4(ha), x1 = ld4(ha + 32 * LDT);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float g0 = ga[2 * s], g1 = ga[32 * LDT + 2 * s];
-        const float x0 = ha[2 * s], x1 = ha[32 * LDT + 2 * s];
-        accW1[0][0] = MFMA(g0, x0, accW1[0][0]);
-        accW1[0][1] = MFMA(g0, x1, accW1[0][1]);
-        accW1[1][0] = MFMA(g1, x0, accW1[1][0]);
-        accW1[1][1] = MFMA(g1, x1, accW1[1][1]);
+        for (int j = 0; j < 4; ++j) {
+          float4 ng0 = g0, ng1 = g1, nx0 = x0, nx1 = x1;
+          if (j + 1 < 4) {
+            ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
+            nx0 = ld4(ha + 8 * (j + 1)); nx1 = ld4(ha + 32 * LDT + 8 * (j + 1));
+          }
+          issue_fence();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            accW1[0][0] = MFMA(f4(g0, i), f4(x0, i), accW1[0][0]);
+            accW1[0][1] = MFMA(f4(g0, i), f4(x1, i), accW1[0][1]);
+            accW1[1][0] = MFMA(f4(g1, i), f4(x0, i), accW1[1][0]);
+            accW1[1][1] = MFMA(f4(g1, i), f4(x1, i), accW1[1][1]);
+          }
+          g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
+        }
       }
       f32x16 t[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[kb][r] = 0.f;
-      const float *wt = sW1 + (4 * half) * LDW + r32;
+      {
+        // t^T[k][row] = sum_n W1[n][k] g^T[n][row]: A = W1^T[k = kb*32 + r32][n], four n per read
+        const float *wt = sW1T + r32 * LDW + 4 * half;
+        float4 a0 = ld4(wt), a1 = ld4(wt + 32 * LDW);
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+        for (int gq = 0; gq < 8; ++gq) {
+          const int nb = gq >> 2, q = gq & 3;
+          float4 n0 = a0, n1 = a1;
+          if (gq + 1 < 8) {
+            const int c = ((gq + 1) >> 2) * 32 + 8 * ((gq + 1) & 3);
+            n0 = ld4(wt + c);
+            n1 = ld4(wt + 32 * LDW + c);
+          }
+          issue_fence();
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const int n = nb * 32 + (s & 3) + 8 * (s >> 2);
-          t[0] = MFMA(wt[n * LDW], g[nb][s], t[0]);
-          t[1] = MFMA(wt[n * LDW + 32], g[nb][s], t[1]);
+          for (int i = 0; i < 4; ++i) {
+            t[0] = MFMA(f4(a0, i), g[nb][4 * q + i], t[0]);
+            t[1] = MFMA(f4(a1, i), g[nb][4 * q + i], t[1]);
+          }
+          a0 = n0; a1 = n1;
         }
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -392,31 +520,43 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     put_tile(sG, g, half, r32);
     wave_lds_fence();
     {
-      const float *ga = sG + r32 * LDT + half, *xa = sX + r32 * LDT + half;
+      const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
+      float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), xv[KB0];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float g0 = ga[2 * s], g1 = ga[32 * LDT + 2 * s];
+      for (int kb = 0; kb < KB0; ++kb) xv[kb] = ld4(xa + kb * 32 * LDT);
 #pragma unroll
-        for (int kb = 0; kb < KB0; ++kb) {
-          const float xv = xa[kb * 32 * LDT + 2 * s];
-          accW0[0][kb] = MFMA(g0, xv, accW0[0][kb]);
-          accW0[1][kb] = MFMA(g1, xv, accW0[1][kb]);
+      for (int j = 0; j < 4; ++j) {
+        float4 ng0 = g0, ng1 = g1, nx[KB0];
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) nx[kb] = xv[kb];
+        if (j + 1 < 4) {
+          ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
+#pragma unroll
+          for (int kb = 0; kb < KB0; ++kb) nx[kb] = ld4(xa + kb * 32 * LDT + 8 * (j + 1));
         }
+        issue_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int kb = 0; kb < KB0; ++kb) {
+            accW0[0][kb] = MFMA(f4(g0, i), f4(xv[kb], i), accW0[0][kb]);
+            accW0[1][kb] = MFMA(f4(g1, i), f4(xv[kb], i), accW0[1][kb]);
+          }
+        g0 = ng0; g1 = ng1;
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) xv[kb] = nx[kb];
       }
     }
     wave_lds_fence();     // the next strip overwrites sX / sG
   }
 
+  STAMP(2);
   // =========================================================================== partials out
-  // Everything below runs once per workgroup.  sT is re-used: red[64 * 64] for the weight
-  // tiles, then vsum[4 waves][4 vectors][64] for the per-feature vectors.
+  // Everything below runs once per workgroup and re-uses the per-wave scratch regions of sT.
   float *part = P.ws + ((int64_t)net * gridDim.x + blockIdx.x) * P.pstride;
-  float *red = sT;
-  float *vsum = sT + 64 * 64;
 
   // per-lane partial vectors (db0, db1, dWL[n]) -> per-feature sums over the wave's 32 rows:
-  // transpose through the wave's own tile (sG lies inside sT, so first everyone leaves the loop)
-  __syncthreads();
+  // transposed through the wave's own tile
   float vec_db0, vec_db1 = 0.f, vec_wl[NO];
   {
     put_tile(sG, db0, half, r32);
@@ -453,29 +593,27 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     sc[2 + NO + n] = trl_wave_sum(dbL[n]);
   }
 
-  // ---- weight tiles: the four waves' accumulators added in wave order through LDS
+  // ---- weight tiles: every wave puts its accumulators into its own scratch region, then the
+  // workgroup adds the four copies in wave order
+  float *mine = sT + wave * WTP;
   auto flush_tile = [&](auto &acc, int KBn, int N, int K, int off) {
-    for (int wv = 0; wv < 4; ++wv) {
-      __syncthreads();
-      if (wave == wv) {
+    const int ld = 32 * KBn;
+    __syncthreads();     // the regions are free (previous flush / the per-wave transposes)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            if (kb < KBn) {
+      for (int kb = 0; kb < 2; ++kb) {
+        if (kb < KBn) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int idx = (nb * 32 + feat(r, half)) * 64 + kb * 32 + r32;
-                red[idx] = wv == 0 ? acc(nb, kb)[r] : red[idx] + acc(nb, kb)[r];
-              }
-            }
-          }
+          for (int r = 0; r < 16; ++r) mine[(nb * 32 + feat(r, half)) * ld + kb * 32 + r32] = acc(nb, kb)[r];
+        }
       }
-    }
     __syncthreads();
-    for (int e = tid; e < N * K; e += 256) part[off + e] = red[(e / K) * 64 + (e % K)];
+    for (int e = tid; e < N * K; e += 256) {
+      const int i = (e / K) * ld + (e % K);
+      part[off + e] = ((sT[i] + sT[WTP + i]) + sT[2 * WTP + i]) + sT[3 * WTP + i];
+    }
   };
-  __syncthreads();     // every wave is done with its own tile region
   {
     auto acc0 = [&](int nb, int kb) -> f32x16 & { return accW0[nb][kb < KB0 ? kb : 0]; };
     flush_tile(acc0, KB0, H1, K0, a.poff[0]);
@@ -485,45 +623,40 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     flush_tile(acc1, 2, a.dims[2], H1, a.poff[1]);
   }
   __syncthreads();
-  // ---- per-feature vectors and scalars: [wave][slot][64], summed in wave order
-  vsum[(wave * 4 + 0) * 64 + lane] = vec_db0;
-  vsum[(wave * 4 + 1) * 64 + lane] = vec_db1;
-  __syncthreads();
-  if (tid < 64) {
-    const float s0 = ((vsum[(0 * 4 + 0) * 64 + tid] + vsum[(1 * 4 + 0) * 64 + tid]) + vsum[(2 * 4 + 0) * 64 + tid]) +
-                     vsum[(3 * 4 + 0) * 64 + tid];
-    if (tid < H1) part[a.poff[0] + H1 * K0 + tid] = s0;
-    if (D == 3) {
-      const float s1 = ((vsum[(0 * 4 + 1) * 64 + tid] + vsum[(1 * 4 + 1) * 64 + tid]) + vsum[(2 * 4 + 1) * 64 + tid]) +
-                       vsum[(3 * 4 + 1) * 64 + tid];
-      if (tid < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + tid] = s1;
-    }
-  }
+  // ---- per-feature vectors [wave][slot][64] and scalars [wave][16], summed in wave order
+  float *vsum = sT, *scal = sT + 4 * 8 * 64;
+  vsum[(wave * 8 + 0) * 64 + lane] = vec_db0;
+  vsum[(wave * 8 + 1) * 64 + lane] = vec_db1;
 #pragma unroll
-  for (int n = 0; n < NO; ++n) {
-    __syncthreads();
-    vsum[(wave * 4 + 0) * 64 + lane] = vec_wl[n];
-    __syncthreads();
-    if (tid < HL && n < NOr)
-      part[a.poff[D - 1] + n * HL + tid] =
-          ((vsum[(0 * 4 + 0) * 64 + tid] + vsum[(1 * 4 + 0) * 64 + tid]) + vsum[(2 * 4 + 0) * 64 + tid]) +
-          vsum[(3 * 4 + 0) * 64 + tid];
-  }
-  __syncthreads();
+  for (int n = 0; n < NO; ++n) vsum[(wave * 8 + 2 + n) * 64 + lane] = vec_wl[n];
   if (lane == 0) {
 #pragma unroll
-    for (int j = 0; j < 2 + 2 * NO; ++j) vsum[wave * 16 + j] = sc[j];
+    for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
   }
   __syncthreads();
-  if (tid < 2 + 2 * NO) {
-    const float s = ((vsum[0 * 16 + tid] + vsum[1 * 16 + tid]) + vsum[2 * 16 + tid]) + vsum[3 * 16 + tid];
-    if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
-      if (tid < 2 + A) part[a.nparams + tid] = s;
-    } else {                                  // dbL[n]
-      const int n = tid - 2 - NO;
-      if (n < NOr) part[a.poff[D - 1] + NOr * HL + n] = s;
+  for (int sl = tid >> 6; sl < 2 + NO; sl += 4) {
+    const int f = tid & 63;
+    const float v = ((vsum[(0 * 8 + sl) * 64 + f] + vsum[(1 * 8 + sl) * 64 + f]) + vsum[(2 * 8 + sl) * 64 + f]) +
+                    vsum[(3 * 8 + sl) * 64 + f];
+    if (sl == 0) {
+      if (f < H1) part[a.poff[0] + H1 * K0 + f] = v;
+    } else if (sl == 1) {
+      if (D == 3 && f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
+    } else {
+      const int n = sl - 2;
+      if (f < HL && n < NOr) part[a.poff[D - 1] + n * HL + f] = v;
     }
   }
+  if (tid < 2 + 2 * NO) {
+    const float v = ((scal[0 * 16 + tid] + scal[1 * 16 + tid]) + scal[2 * 16 + tid]) + scal[3 * 16 + tid];
+    if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
+      if (tid < 2 + A) part[a.nparams + tid] = v;
+    } else {                                  // dbL[n]
+      const int n = tid - 2 - NO;
+      if (n < NOr) part[a.poff[D - 1] + NOr * HL + n] = v;
+    }
+  }
+  STAMP(3);
 }
 
 // ---- second launch: sums the partial sets of every workgroup in a fixed order and writes
