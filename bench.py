@@ -54,7 +54,10 @@ def parse():
   ap.add_argument('--kernel-iters', type=int, default=50)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
-  ap.add_argument('--no-graph', action='store_true', help='eager learn() instead of HIP-graph replay')
+  ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                  help='HIP-graph replay of learn(); auto = off for ppo (its whole step is one fused launch + a '
+                       'reduce, eager issue keeps up), on for the off-policy loops')
+  ap.add_argument('--no-graph', action='store_true', help='same as --graph off')
   return ap.parse_args()
 
 
@@ -163,7 +166,7 @@ def bench_ppo(args, rank, world, dev):
   warmup = args.warmup if args.warmup is not None else 1
   torch.manual_seed(0)
   ctl = PPOController(obs_size, act_size, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3,
-                      clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden, graph=not args.no_graph)
+                      clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden, graph=args.use_graph)
   trace('controller built')
   obs, action, reward, done, last_next_obs = make_rollout(T, N, obs_size, act_size, dev, 1234 + rank)
   last_done = done[-1]
@@ -245,7 +248,8 @@ def bench_ppo(args, rank, world, dev):
       'config': {'workload': 'ppo_gae_clip: T=%d, N_envs=%d per GPU, MLP %s, obs 3, act 1' % (T, N, args.hidden),
                  'minibatch': B, 'n_epochs': args.epochs, 'learn_calls_per_step': args.epochs * ((n + B - 1) // B),
                  'gamma': 0.99, 'lmbda': 0.95, 'clip_ratio': 0.2, 'parallelism': 'dp%d' % world,
-                 'learn_step': 'eager' if args.no_graph else 'hip-graph replay'},
+                 'learn_step': ('hip-graph replay' if args.use_graph else 'eager') +
+                 (': fused fwd+loss+bwd launch, reduce(+clip+Adam) launch' if ctl._fused is not None else '')},
       'roofline': roof,
   }
   res.update(extra)
@@ -347,7 +351,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
               (torch.rand(k, 1, device=dev, generator=g) < 0.005).float()]
     fill_ring(ds, cap, cols, 8192)
     ctl = DQNController(28224, 6, double_dqn=True, gamma=0.99, lr=1e-3, n_update_interval=10, device=dev,
-                        graph=not args.no_graph)
+                        graph=args.use_graph)
     row_bytes, name = 2 * 28224 + 12, 'double_dqn_atari'
     wl = 'double_dqn: %d-row replay of 84x84x4 u8 frames per GPU (%.0f GB), flat-frame QNet 28224-128-128-6' % (
         cap, cap * ds.row_bytes / 1e9)
@@ -361,7 +365,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
               (torch.rand(k, 1, device=dev, generator=g) < 0.01).float()]
     fill_ring(ds, cap, cols, 1 << 18)
     ctl = DDPGController(3, 1, -2.0, 2.0, actor_lr=1e-4, critic_lr=1e-3, gamma=0.99, tau=1e-2, device=dev,
-                         graph=not args.no_graph)
+                         graph=args.use_graph)
     row_bytes, name = 36, 'ddpg_pendulum'
     wl = 'ddpg: %d-row Pendulum-shaped f32 replay per GPU, actor/critic MLP 256x256' % cap
 
@@ -386,7 +390,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix (bit-exact)',
                  'parallelism': 'dp%d' % world, 'name': name,
-                 'learn_step': 'eager' if args.no_graph else 'hip-graph replay'},
+                 'learn_step': 'hip-graph replay' if args.use_graph else 'eager'},
       'roofline': roof,
   }
   return res, dict(cap=cap, B=B, atari=atari)
@@ -431,6 +435,9 @@ def cpu_baseline_offpolicy(info):
 
 def main():
   args = parse()
+  if args.no_graph:
+    args.graph = 'off'
+  args.use_graph = args.graph == 'on' or (args.graph == 'auto' and args.workload != 'ppo')
   rank, local, world = setup_dist(args)
   dev = torch.device('cuda', local)
   if args.workload == 'ppo':

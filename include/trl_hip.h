@@ -257,14 +257,28 @@ int trl_mlp_bwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *x
  *   losses_out[0..3] = actor, critic, entropy, actor + alpha * critic - beta * entropy.
  *   critic_grads / actor_grads: 2 * depth destinations (dW_0, db_0, dW_1, ...), e.g. the .grad
  *   views of a flat gradient buffer, OVERWRITTEN with d loss / d parameter;  dlog_std [A] likewise.
- * `ws`: trl_ppo_learn_workspace_bytes() bytes of device scratch.  clip_grad_value_ and Adam
- * (ppo_controller.py:72-74) are trl_adam_step, after the all-reduce when there is one. */
+ * `ws`: trl_ppo_learn_workspace_bytes() bytes of device scratch.
+ * `adam` (may be NULL): also apply clip_grad_value_ + Adam (ppo_controller.py:72-74; the update of
+ * trl_adam_step, same arithmetic) to every parameter inside the reduce launch, for the single-rank
+ * learner.  It names four parallel flat f32 buffers of `n` floats; every gradient destination above
+ * must lie inside `grad`, and the parameter / moments of a gradient element are the elements at the
+ * same offset of `param` / `exp_avg` / `exp_avg_sq` (the layout of one flat buffer per quantity).
+ * With an all-reduce between backward and update, pass NULL and call trl_adam_step afterwards. */
+typedef struct {
+  float *param, *grad, *exp_avg, *exp_avg_sq;
+  int64_t n;
+  double lr, beta1, beta2, eps;
+  int64_t step;      /* 1-based count of this update */
+  double grad_scale; /* 1 = none */
+  double clip_value; /* <= 0 = none */
+} trl_adam_args;
+
 int64_t trl_ppo_learn_workspace_bytes(const trl_mlp_desc *critic, const trl_mlp_desc *actor, int64_t B);
 int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
                         const float *obs, const float *action, const float *returns, const float *old_logp,
                         const float *adv, int64_t B, int32_t A, double clip, double alpha, double beta,
                         float *losses_out, float *const *critic_grads, float *const *actor_grads,
-                        float *dlog_std, void *ws, void *stream);
+                        float *dlog_std, const trl_adam_args *adam, void *ws, void *stream);
 
 #ifdef __cplusplus
 }

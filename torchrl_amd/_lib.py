@@ -36,6 +36,13 @@ class MlpDesc(C.Structure):
   _fields_ = [('depth', C.c_int32), ('dims', C.c_int32 * 4), ('w', C.c_void_p * 3), ('b', C.c_void_p * 3)]
 
 
+class AdamArgs(C.Structure):
+  """mirror of trl_adam_args"""
+  _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
+              ('n', C.c_int64), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
+              ('step', C.c_int64), ('grad_scale', C.c_double), ('clip_value', C.c_double)]
+
+
 class TrlError(RuntimeError):
   pass
 
@@ -75,7 +82,8 @@ PROTOTYPES = {
                                     C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     'trl_ppo_learn_workspace_bytes': (_i64, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _i64]),
     'trl_ppo_learn_fused': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                      _i32, _f64, _f64, _f64, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp]),
+                                      _i32, _f64, _f64, _f64, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(AdamArgs),
+                                      _vp, _vp]),
 }
 
 _lib = None

@@ -84,8 +84,11 @@ class PPOController(Controller):
   def _learn_body(self, obs, action, returns, old_log_probs, advantages):
     """Device work of one learn(): forward, fused loss, backward and (single rank) the update."""
     if self._fused is not None and self._fused.usable(obs):
-      losses = self._fused(obs, action, returns, old_log_probs, advantages, self.clip_ratio, self.alpha, self.beta)
-      if not self._sync.enabled:
+      solo = not self._sync.enabled
+      in_kernel = solo and not self.ac_net_optim.device_state    # eager single rank: update inside the reduce launch
+      losses = self._fused(obs, action, returns, old_log_probs, advantages, self.clip_ratio, self.alpha, self.beta,
+                           adam=self.ac_net_optim if in_kernel else None)
+      if solo and not in_kernel:
         self.ac_net_optim.step()
       return losses[:3]
     value, mean, log_std = self.ac_net.heads(obs)

@@ -51,3 +51,47 @@ __device__ __forceinline__ float trl_block_sum(float v, float *red) {
   for (int i = 0; i < NW; ++i) s += red[i];
   return s;
 }
+
+// ---- torch.optim.Adam's default single-tensor update on one element, shared by the flat-buffer
+// update kernels (trl_loss.hip) and the fused learner step's reduce launch (trl_learn.hip).
+struct TrlAdamScalars {
+  float w1;        // 1 - beta1            (exp_avg.lerp_ weight)
+  float beta2;     //                      (exp_avg_sq.mul_)
+  float c2;        // 1 - beta2            (addcmul_ value)
+  float bc2_sqrt;  // sqrt(1 - beta2^step)
+  float eps;
+  float neg_step;  // -(lr / (1 - beta1^step))
+  float scale;     // gradient scale (1 = none)
+  float clip;      // clamp bound (<= 0 = none)
+};
+
+#include <math.h>
+static inline __host__ __device__ TrlAdamScalars trl_adam_scalars(double lr, double beta1, double beta2, double eps,
+                                                                  int64_t step, double grad_scale, double clip_value) {
+  TrlAdamScalars s;
+  s.w1 = (float)(1.0 - beta1);
+  s.beta2 = (float)beta2;
+  s.c2 = (float)(1.0 - beta2);
+  s.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  s.eps = (float)eps;
+  s.neg_step = (float)(-(lr / (1.0 - pow(beta1, (double)step))));
+  s.scale = (float)grad_scale;
+  s.clip = (float)clip_value;
+  return s;
+}
+
+// scale + clamp the gradient (written back when changed), then lerp_ / mul_().addcmul_() / addcdiv_
+// in torch's op order, one f32 rounding per op
+__device__ __forceinline__ void trl_adam_elem(float *p, float *g, float *m, float *v, const TrlAdamScalars &s) {
+  float gi = *g;
+  if (s.scale != 1.0f) gi = __fmul_rn(gi, s.scale);
+  if (s.clip > 0.f) gi = fminf(fmaxf(gi, -s.clip), s.clip);
+  if (s.scale != 1.0f || s.clip > 0.f) *g = gi;
+  float mi = *m, vi = *v;
+  mi = __fadd_rn(mi, __fmul_rn(s.w1, __fsub_rn(gi, mi)));
+  vi = __fadd_rn(__fmul_rn(vi, s.beta2), __fmul_rn(__fmul_rn(s.c2, gi), gi));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), s.bc2_sqrt), s.eps);
+  *p = __fadd_rn(*p, __fdiv_rn(__fmul_rn(s.neg_step, mi), denom));
+  *m = mi;
+  *v = vi;
+}

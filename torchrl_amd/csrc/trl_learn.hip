@@ -677,6 +677,10 @@ struct ReduceArgs {
   int64_t B;
   int32_t A;
   float alpha, beta, dls_ent;
+  // optional update stage: param / moments of gradient element g are at (g - grad) in these
+  int32_t do_adam;
+  float *p, *g, *m, *v;
+  TrlAdamScalars adam;
 };
 
 __global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_blocks) {
@@ -699,7 +703,14 @@ __global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_bl
       const GradDst &gd = R.gd[net];
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        if (j < gd.nseg && i >= gd.start[j] && i < gd.start[j + 1]) gd.dst[j][i - gd.start[j]] = t;
+        if (j < gd.nseg && i >= gd.start[j] && i < gd.start[j + 1]) {
+          float *gp = gd.dst[j] + (i - gd.start[j]);
+          *gp = t;
+          if (R.do_adam) {
+            const int64_t o = gp - R.g;
+            trl_adam_elem(R.p + o, gp, R.m + o, R.v + o, R.adam);
+          }
+        }
     }
     return;
   }
@@ -731,7 +742,14 @@ __global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_bl
     R.losses[2] = ent;
     R.losses[3] = (actor + R.alpha * critic) - R.beta * ent;
   }
-  if ((int)threadIdx.x < R.A && threadIdx.x < 5) R.dlog_std[threadIdx.x] = partS[0][3 + threadIdx.x] + R.dls_ent;
+  if ((int)threadIdx.x < R.A && threadIdx.x < 5) {
+    float *gp = R.dlog_std + threadIdx.x;
+    *gp = partS[0][3 + threadIdx.x] + R.dls_ent;
+    if (R.do_adam) {
+      const int64_t o = gp - R.g;
+      trl_adam_elem(R.p + o, gp, R.m + o, R.v + o, R.adam);
+    }
+  }
 }
 
 int fill_net(const char *fn, const trl_mlp_desc *d, int out_max, NetArgs *a) {
@@ -799,7 +817,8 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
                                    const float *obs, const float *action, const float *returns,
                                    const float *old_logp, const float *adv, int64_t B, int32_t A, double clip,
                                    double alpha, double beta, float *losses_out, float *const *critic_grads,
-                                   float *const *actor_grads, float *dlog_std, void *ws, void *stream) {
+                                   float *const *actor_grads, float *dlog_std, const trl_adam_args *adam, void *ws,
+                                   void *stream) {
   const char *fn = "trl_ppo_learn_fused";
   TRL_REQUIRE(log_std && obs && action && returns && old_logp && adv && losses_out && critic_grads && actor_grads &&
                   dlog_std && ws,
@@ -832,6 +851,20 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
   if (rc) return rc;
   R.losses = losses_out; R.dlog_std = dlog_std; R.B = B; R.A = A;
   R.alpha = P.alpha; R.beta = P.beta; R.dls_ent = (float)(-beta / (double)A);
+  if (adam) {
+    TRL_REQUIRE(adam->param && adam->grad && adam->exp_avg && adam->exp_avg_sq && adam->n > 0 && adam->step >= 1,
+                "%s: incomplete adam arguments", fn);
+    const float *lo = adam->grad, *hi = adam->grad + adam->n;
+    bool inside = dlog_std >= lo && dlog_std + A <= hi;
+    for (int g = 0; g < 2; ++g)
+      for (int j = 0; j < R.gd[g].nseg; ++j)
+        inside = inside && R.gd[g].dst[j] >= lo && R.gd[g].dst[j] + (R.gd[g].start[j + 1] - R.gd[g].start[j]) <= hi;
+    TRL_REQUIRE(inside, "%s: with adam, every gradient destination must lie inside adam->grad", fn);
+    R.do_adam = 1;
+    R.p = adam->param; R.g = adam->grad; R.m = adam->exp_avg; R.v = adam->exp_avg_sq;
+    R.adam = trl_adam_scalars(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->grad_scale,
+                              adam->clip_value);
+  }
 
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)nwg, 2), block(256);

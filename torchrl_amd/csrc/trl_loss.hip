@@ -352,33 +352,13 @@ __global__ __launch_bounds__(NT) void k_a2c_finalize(const float *__restrict__ w
 }
 
 // ------------------------------------------------------------------------------ update
-struct AdamScalars {
-  float w1;        // 1 - beta1            (exp_avg.lerp_ weight)
-  float beta2;     //                      (exp_avg_sq.mul_)
-  float c2;        // 1 - beta2            (addcmul_ value)
-  float bc2_sqrt;  // sqrt(1 - beta2^step)
-  float eps;
-  float neg_step;  // -(lr / (1 - beta1^step))
-  float scale;     // gradient scale (1 = none)
-  float clip;      // clamp bound (<= 0 = none)
-};
+typedef TrlAdamScalars AdamScalars;
 
 __global__ __launch_bounds__(NT) void k_adam(float *__restrict__ p, float *__restrict__ g,
                                              float *__restrict__ m, float *__restrict__ v, int64_t n,
                                              AdamScalars s) {
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-    float gi = g[i];
-    if (s.scale != 1.0f) gi = __fmul_rn(gi, s.scale);
-    if (s.clip > 0.f) gi = fminf(fmaxf(gi, -s.clip), s.clip);
-    if (s.scale != 1.0f || s.clip > 0.f) g[i] = gi;
-    float mi = m[i], vi = v[i];
-    mi = __fadd_rn(mi, __fmul_rn(s.w1, __fsub_rn(gi, mi)));                 // lerp_(grad, 1 - beta1)
-    vi = __fadd_rn(__fmul_rn(vi, s.beta2), __fmul_rn(__fmul_rn(s.c2, gi), gi));  // mul_().addcmul_()
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), s.bc2_sqrt), s.eps);
-    p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(s.neg_step, mi), denom));    // addcdiv_
-    m[i] = mi;
-    v[i] = vi;
-  }
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+    trl_adam_elem(p + i, g + i, m + i, v + i, s);
 }
 
 // graph-replay form: scalars derived on the device from the device-resident step counter
@@ -386,15 +366,7 @@ __global__ void k_adam_prep(trl_adam_state *st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int64_t step = st->step + 1;
     st->step = step;
-    AdamScalars s;
-    s.w1 = (float)(1.0 - st->beta1);
-    s.beta2 = (float)st->beta2;
-    s.c2 = (float)(1.0 - st->beta2);
-    s.bc2_sqrt = (float)sqrt(1.0 - pow(st->beta2, (double)step));
-    s.eps = (float)st->eps;
-    s.neg_step = (float)(-(st->lr / (1.0 - pow(st->beta1, (double)step))));
-    s.scale = (float)st->grad_scale;
-    s.clip = (float)st->clip_value;
+    const AdamScalars s = trl_adam_scalars(st->lr, st->beta1, st->beta2, st->eps, step, st->grad_scale, st->clip_value);
     *(AdamScalars *)st->derived = s;
   }
 }
@@ -403,19 +375,8 @@ __global__ __launch_bounds__(NT) void k_adam_dev(float *__restrict__ p, float *_
                                                  float *__restrict__ m, float *__restrict__ v, int64_t n,
                                                  const trl_adam_state *__restrict__ st) {
   const AdamScalars s = *(const AdamScalars *)st->derived;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-    float gi = g[i];
-    if (s.scale != 1.0f) gi = __fmul_rn(gi, s.scale);
-    if (s.clip > 0.f) gi = fminf(fmaxf(gi, -s.clip), s.clip);
-    if (s.scale != 1.0f || s.clip > 0.f) g[i] = gi;
-    float mi = m[i], vi = v[i];
-    mi = __fadd_rn(mi, __fmul_rn(s.w1, __fsub_rn(gi, mi)));
-    vi = __fadd_rn(__fmul_rn(vi, s.beta2), __fmul_rn(__fmul_rn(s.c2, gi), gi));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), s.bc2_sqrt), s.eps);
-    p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(s.neg_step, mi), denom));
-    m[i] = mi;
-    v[i] = vi;
-  }
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+    trl_adam_elem(p + i, g + i, m + i, v + i, s);
 }
 
 __global__ __launch_bounds__(NT) void k_polyak(float *__restrict__ t, const float *__restrict__ s, int64_t n,
@@ -543,15 +504,7 @@ extern "C" int trl_adam_step(float *param, float *grad, float *exp_avg, float *e
   TRL_REQUIRE(param && grad && exp_avg && exp_avg_sq, "%s: null pointer", fn);
   TRL_REQUIRE(n >= 0 && step >= 1, "%s: need n >= 0 and step >= 1", fn);
   if (n == 0) return TRL_OK;
-  AdamScalars s;
-  s.w1 = (float)(1.0 - beta1);
-  s.beta2 = (float)beta2;
-  s.c2 = (float)(1.0 - beta2);
-  s.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
-  s.eps = (float)eps;
-  s.neg_step = (float)(-(lr / (1.0 - pow(beta1, (double)step))));
-  s.scale = (float)grad_scale;
-  s.clip = (float)clip_value;
+  const AdamScalars s = trl_adam_scalars(lr, beta1, beta2, eps, step, grad_scale, clip_value);
   hipLaunchKernelGGL(k_adam, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, n, s);
   TRL_CHECK_LAUNCH(fn);

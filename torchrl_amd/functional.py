@@ -524,7 +524,9 @@ class FusedPpoLearn:
     return obs.is_cuda and obs.dim() == 2 and obs.dtype == torch.float32 and obs.shape[0] >= self.MIN_BATCH \
         and obs.shape[1] == self.K0
 
-  def __call__(self, obs, action, returns, old_logp, adv, clip, alpha, beta):
+  def __call__(self, obs, action, returns, old_logp, adv, clip, alpha, beta, adam=None):
+    """adam: an optim.FlatAdam over the flat buffers holding these parameters -> clip + Adam run
+    inside the reduce launch (its step count is advanced here); None -> gradients only."""
     C = self._C
     B = obs.shape[0]
     obs = _f32c(obs, 'obs')
@@ -540,10 +542,13 @@ class FusedPpoLearn:
     lib = _lib.lib()
     ws = _linear_ws(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
     losses = torch.empty(4, dtype=torch.float32, device=dev)
+    aref = None
+    if adam is not None:
+      aref = C.byref(adam.fused_args())
     with torch.cuda.device(dev):
       _lib.check(lib.trl_ppo_learn_fused(
           C.byref(self.descs[0]), C.byref(self.descs[1]), self.log_std.data_ptr(), obs.data_ptr(),
           action.data_ptr(), returns.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), B, self.A, float(clip),
           float(alpha), float(beta), losses.data_ptr(), self.gradp[0], self.gradp[1],
-          self.log_std.grad.data_ptr(), ws.data_ptr(), _lib.stream_ptr(dev)))
+          self.log_std.grad.data_ptr(), aref, ws.data_ptr(), _lib.stream_ptr(dev)))
     return losses

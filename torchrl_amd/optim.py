@@ -127,6 +127,22 @@ class FlatAdam:
       F.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
                    self.lr, self.betas, self.eps, self.grad_scale, self.clip_value)
 
+  def fused_args(self):
+    """trl_adam_args for a kernel that applies this update itself (trl_ppo_learn_fused): advances
+    the host step count, like step().  Not for device_state (graph) mode."""
+    if self.device_state:
+      raise _lib.TrlError('fused Adam is for the eager step (graph mode keeps its step count on the device)')
+    self.step_count += 1
+    a = getattr(self, '_fused_args', None)
+    if a is None:
+      a = self._fused_args = _lib.AdamArgs()
+    a.param, a.grad = self.flat.data.data_ptr(), self.flat.grad.data_ptr()
+    a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+    a.n = self.flat.numel
+    a.lr, a.beta1, a.beta2, a.eps = self.lr, self.betas[0], self.betas[1], self.eps
+    a.step, a.grad_scale, a.clip_value = self.step_count, self.grad_scale, self.clip_value
+    return a
+
   def note_step(self):
     """Host mirror of the device step counter: call once per optimizer step when
     device_state=True (the step itself may have been a graph replay)."""
