@@ -280,6 +280,15 @@ int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         float *losses_out, float *const *critic_grads, float *const *actor_grads,
                         float *dlog_std, const trl_adam_args *adam, void *ws, void *stream);
 
+/* The forward alone of the same networks over B rows, only the outputs written: the value /
+ * mean / log-prob pass of PPOController.compute_return (ppo_controller.py:34, 48) and act().
+ *   value [B] (needs critic), mean [B, A], logp [B, A] = Normal(mean, exp(log_std)).log_prob(action)
+ *   per dimension (need actor; logp also action [B, A] and log_std [A]); any output may be NULL.
+ * Depth 2 or 3, widths <= 64, 1 <= A <= 4. */
+int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                          const float *obs, const float *action, int64_t B, int32_t A, float *value, float *mean,
+                          float *logp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,43 @@ def test_fused_learn_is_reproducible_and_rejects_bad_shapes():
     ctl._fused(obs, act[:100], ret, old, adv, 0.2, 0.5, 1e-3)
   assert PPOController(3, 1, device=DEV, hidden=(128, 64))._fused is None              # too wide: general path
   assert PPOController(3, 3, device=DEV, hidden=(64, 64))._fused is None               # A > 2 with two hidden layers
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B', [(3, 1, (64, 64), 70001), (4, 2, (64, 64), 4096), (40, 2, (48, 33), 999),
+                                                 (5, 4, (64,), 12345), (64, 1, (64, 64), 300)])
+def test_fused_forward_matches_torch(obs_size, A, hidden, B):
+  """trl_ppo_forward_fused (value / mean / log-prob, outputs only) vs the torch modules."""
+  torch.manual_seed(B)
+  ctl = PPOController(obs_size, A, device=DEV, hidden=hidden)
+  with torch.no_grad():
+    ctl.ac_net.log_std.add_(torch.linspace(-0.4, 0.3, A, device=DEV).view(1, A))
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  obs, act = torch.randn(B, obs_size), torch.randn(B, A)
+  with torch.no_grad():
+    ev, em = ref.critic(obs), ref.actor(obs)
+    elp = torch.distributions.Normal(em, ref.log_std.exp().expand_as(em)).log_prob(act)
+  value, mean, logp = ctl._fused.forward(obs.to(DEV), act.to(DEV))
+  torch.testing.assert_close(value.cpu(), ev.view(-1), rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(mean.cpu(), em, rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(logp.cpu(), elp, rtol=1e-5, atol=1e-5)
+  v2, m2, l2 = ctl._fused.forward(obs.to(DEV), want_mean=False)
+  assert m2 is None and l2 is None and torch.equal(v2, value)
+
+
+def test_compute_return_fused_equals_general_path(monkeypatch):
+  """compute_return_batched through the forward-only kernel == through the general path."""
+  outs = []
+  g = torch.Generator().manual_seed(9)
+  T, N = 64, 40
+  obs, act = torch.randn(T, N, 3, generator=g).to(DEV), torch.randn(T, N, 1, generator=g).to(DEV)
+  rew, last = torch.randn(T, N, generator=g).to(DEV), torch.randn(N, 3, generator=g).to(DEV)
+  last_done = (torch.rand(N, generator=g) < 0.3).float().to(DEV)
+  for mode in ('1', '0'):
+    monkeypatch.setenv('TRL_FUSED_LEARN', mode)
+    torch.manual_seed(4)
+    ctl = PPOController(3, 1, gamma=0.99, lmbda=0.95, device=DEV, hidden=(64, 64))
+    if ctl._fused is not None:
+      ctl._fused.MIN_BATCH = 1
+    outs.append(ctl.compute_return_batched(obs, act, rew, last, last_done))
+  for a, b in zip(outs[0], outs[1]):
+    torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)

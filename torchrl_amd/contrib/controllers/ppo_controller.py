@@ -72,6 +72,15 @@ class PPOController(Controller):
     T, N = reward.shape
     with torch.no_grad():
       flat_obs = obs.reshape(T * N, -1)
+      if self._fused is not None and self._fused.usable(flat_obs) and self._fused.usable(last_next_obs):
+        # forward-only kernel: values and log-probs straight from registers, no activations written
+        values, _, log_probs = self._fused.forward(flat_obs, action.reshape(T * N, -1), want_mean=False)
+        bootstrap, _, _ = self._fused.forward(last_next_obs, want_mean=False)
+        bootstrap = torch.where(last_done.reshape(N) != 0, torch.zeros_like(bootstrap), bootstrap)
+        values = values.view(T, N)
+        returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
+                             env_major_out=env_major_out)
+        return returns, adv, log_probs.view(T, N, -1), values
       values, mean, log_std = self.ac_net.heads(flat_obs)
       values = values.view(T, N)
       bootstrap = self.ac_net.critic(last_next_obs).view(N)

@@ -133,6 +133,120 @@ __device__ __forceinline__ void put_tile(float *tile, const f32x16 (&v)[2], int 
     for (int r = 0; r < 16; ++r) tile[(nb * 32 + feat(r, half)) * LDT + r32] = v[nb][r];
 }
 
+// ---- forward pieces, shared by the learner kernel and the inference kernel
+// layer 0: h1^T = relu(W0 x^T + b0); x^T from the strip's LDS tile, k walked in natural order
+template <int LDW0>
+__device__ __forceinline__ void fwd_layer0(f32x16 (&h1)[2], const float *sX, const float *sW0, const float *sB,
+                                           int ksteps0, int half, int r32) {
+  load_feat_vec(h1, sB, half);
+  for (int s = 0; s < ksteps0; ++s) {
+    const int k = 2 * s + half;
+    const float bv = sX[k * LDT + r32];
+    const float a0 = sW0[r32 * LDW0 + k];
+    const float a1 = sW0[(32 + r32) * LDW0 + k];
+    h1[0] = MFMA(a0, bv, h1[0]);
+    h1[1] = MFMA(a1, bv, h1[1]);
+  }
+  relu2(h1);
+}
+
+// layer 1: h2^T = relu(W1 h1^T + b1), the B operand chained in registers.  Group gq = (kb, q) is
+// steps s = 4q .. 4q+3 of k-block kb, i.e. features kb*32 + 8q + 4half + i: one 16 B read per
+// fan-out block, fetched one group ahead
+__device__ __forceinline__ void fwd_layer1(f32x16 (&h2)[2], const f32x16 (&h1)[2], const float *sW1,
+                                           const float *sB1, int half, int r32) {
+  load_feat_vec(h2, sB1, half);
+  const float *wl = sW1 + r32 * LDW + 4 * half;
+  float4 a0 = ld4(wl), a1 = ld4(wl + 32 * LDW);
+#pragma unroll
+  for (int gq = 0; gq < 8; ++gq) {
+    const int kb = gq >> 2, q = gq & 3;
+    float4 n0 = a0, n1 = a1;
+    if (gq + 1 < 8) {
+      const int c = ((gq + 1) >> 2) * 32 + 8 * ((gq + 1) & 3);
+      n0 = ld4(wl + c);
+      n1 = ld4(wl + 32 * LDW + c);
+    }
+    issue_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h2[0] = MFMA(f4(a0, i), h1[kb][4 * q + i], h2[0]);
+      h2[1] = MFMA(f4(a1, i), h1[kb][4 * q + i], h2[1]);
+    }
+    a0 = n0; a1 = n1;
+  }
+  relu2(h2);
+}
+
+// last layer on the VALU: out[n] = WL[n] . hl + bL[n] (both lane halves end with the row's value)
+template <int NO>
+__device__ __forceinline__ void fwd_last(float (&out)[NO], const f32x16 (&hl)[2], const float *sWL,
+                                         const float *sBL, int half) {
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    float p = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
+        p = fmaf(w4.x, hl[kb][4 * q + 0], p);
+        p = fmaf(w4.y, hl[kb][4 * q + 1], p);
+        p = fmaf(w4.z, hl[kb][4 * q + 2], p);
+        p = fmaf(w4.w, hl[kb][4 * q + 3], p);
+      }
+    p += __shfl_xor(p, 32, 64);
+    out[n] = p + sBL[n];
+  }
+}
+
+// weights of one network, zero-padded, into LDS, once per workgroup.  Loads first, stores after:
+// every load of a tile is in flight at once (a load -> store loop pays the L2 latency per iteration)
+template <int D, int LDW0, int NO, bool WITH_T>
+__device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, float *sW1, float *sW1T, float *sWL,
+                                              float *sB, int tid) {
+  const int K0 = a.dims[0], H1 = a.dims[1], HL = a.dims[D - 1], NOr = a.dims[D];
+  {
+    constexpr int N0 = (64 * LDW0 + 255) / 256;
+    float v[N0];
+#pragma unroll
+    for (int i = 0; i < N0; ++i) {
+      const int e = tid + 256 * i, n = e / LDW0, k = e % LDW0;
+      v[i] = (n < H1 && k < K0 && e < 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < N0; ++i)
+      if (tid + 256 * i < 64 * LDW0) sW0[tid + 256 * i] = v[i];
+  }
+  if (D == 3) {
+    const int H2 = a.dims[2];
+    constexpr int N1 = 64 * 64 / 256;
+    float v[N1];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
+      v[i] = (n < H2 && k < H1) ? a.w[1][n * H1 + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
+      sW1[n * LDW + k] = v[i];
+      if (WITH_T) sW1T[k * LDW + n] = v[i];
+    }
+  }
+  for (int e = tid; e < NO * 64; e += 256) {
+    const int n = e >> 6, k = e & 63;
+    sWL[e] = (n < NOr && k < HL) ? a.w[D - 1][n * HL + k] : 0.f;
+  }
+  for (int e = tid; e < 2 * 64 + 4; e += 256) {
+    float v = 0.f;
+    if (e < 64) v = e < H1 ? a.b[0][e] : 0.f;
+    else if (e < 128) v = (D == 3 && e - 64 < a.dims[2]) ? a.b[1][e - 64] : 0.f;
+    else v = e - 128 < NOr ? a.b[D - 1][e - 128] : 0.f;
+    sB[e] = v;
+  }
+}
+
 // D = depth (2: in -> H -> out, 3: in -> H -> H -> out); KB0 = 32-blocks of the fan-in;
 // NO = padded fan-out of the last layer (actual fan-outs <= NO)
 template <int D, int KB0, int NO>
@@ -160,47 +274,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int A = P.A;
 
   STAMP(0);
-  // ---- weights, zero-padded, once per workgroup.  Loads first, stores after: every load of a
-  // tile is in flight at once (a load -> store loop would pay the L2 latency per iteration)
-  {
-    constexpr int N0 = (64 * LDW0 + 255) / 256;
-    float v[N0];
-#pragma unroll
-    for (int i = 0; i < N0; ++i) {
-      const int e = tid + 256 * i, n = e / LDW0, k = e % LDW0;
-      v[i] = (n < H1 && k < K0 && e < 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < N0; ++i)
-      if (tid + 256 * i < 64 * LDW0) sW0[tid + 256 * i] = v[i];
-  }
-  if (D == 3) {
-    const int H2 = a.dims[2];
-    constexpr int N1 = 64 * 64 / 256;
-    float v[N1];
-#pragma unroll
-    for (int i = 0; i < N1; ++i) {
-      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
-      v[i] = (n < H2 && k < H1) ? a.w[1][n * H1 + k] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < N1; ++i) {
-      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
-      sW1[n * LDW + k] = v[i];
-      sW1T[k * LDW + n] = v[i];
-    }
-  }
-  for (int e = tid; e < NO * 64; e += 256) {
-    const int n = e >> 6, k = e & 63;
-    sWL[e] = (n < NOr && k < HL) ? a.w[D - 1][n * HL + k] : 0.f;
-  }
-  for (int e = tid; e < 2 * 64 + 4; e += 256) {
-    float v = 0.f;
-    if (e < 64) v = e < H1 ? a.b[0][e] : 0.f;
-    else if (e < 128) v = (D == 3 && e - 64 < a.dims[2]) ? a.b[1][e - 64] : 0.f;
-    else v = e - 128 < NOr ? a.b[D - 1][e - 128] : 0.f;
-    sB[e] = v;
-  }
+  stage_weights<D, LDW0, NO, true>(a, sW0, sW1, sW1T, sWL, sB, tid);
   float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
   float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
   float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T
@@ -328,65 +402,13 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     if (strip + sstride < nstrips) fetch(strip + sstride);
     wave_lds_fence();
 
-    // ---- layer 0: h1^T = relu(W0 x^T + b0)
-    f32x16 h1[2];
-    load_feat_vec(h1, sB, half);
-    for (int s = 0; s < ksteps0; ++s) {
-      const int k = 2 * s + half;
-      const float bv = sX[k * LDT + r32];
-      const float a0 = sW0[r32 * LDW0 + k];
-      const float a1 = sW0[(32 + r32) * LDW0 + k];
-      h1[0] = MFMA(a0, bv, h1[0]);
-      h1[1] = MFMA(a1, bv, h1[1]);
-    }
-    relu2(h1);
-
-    // ---- layer 1 (D == 3): h2^T = relu(W1 h1^T + b1), operands chained in registers
-    f32x16 h2[2];
-    if (D == 3) {
-      load_feat_vec(h2, sB + 64, half);
-      // group gq = (kb, q): steps s = 4q .. 4q+3 of k-block kb, i.e. features kb*32 + 8q + 4half + i
-      const float *wl = sW1 + r32 * LDW + 4 * half;
-      float4 a0 = ld4(wl), a1 = ld4(wl + 32 * LDW);
-#pragma unroll
-      for (int gq = 0; gq < 8; ++gq) {
-        const int kb = gq >> 2, q = gq & 3;
-        float4 n0 = a0, n1 = a1;
-        if (gq + 1 < 8) {
-          const int c = ((gq + 1) >> 2) * 32 + 8 * ((gq + 1) & 3);
-          n0 = ld4(wl + c);
-          n1 = ld4(wl + 32 * LDW + c);
-        }
-        issue_fence();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          h2[0] = MFMA(f4(a0, i), h1[kb][4 * q + i], h2[0]);
-          h2[1] = MFMA(f4(a1, i), h1[kb][4 * q + i], h2[1]);
-        }
-        a0 = n0; a1 = n1;
-      }
-      relu2(h2);
-    }
+    // ---- forward: h1, (h2), out
+    f32x16 h1[2], h2[2];
+    fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+    if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
     const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
-
-    // ---- last layer on the VALU: out[n] = WL[n] . hl + bL[n]
     float out[NO];
-#pragma unroll
-    for (int n = 0; n < NO; ++n) {
-      float p = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
-          p = fmaf(w4.x, hl[kb][4 * q + 0], p);
-          p = fmaf(w4.y, hl[kb][4 * q + 1], p);
-          p = fmaf(w4.z, hl[kb][4 * q + 2], p);
-          p = fmaf(w4.w, hl[kb][4 * q + 3], p);
-        }
-      p += __shfl_xor(p, 32, 64);
-      out[n] = p + sB[128 + n];
-    }
+    fwd_last<NO>(out, hl, sWL, sB + 128, half);
 
     // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
     float gout[NO];
@@ -659,6 +681,139 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   STAMP(3);
 }
 
+// ---- inference: the forward alone over B rows (PPOController.compute_return's value / mean /
+// log-prob pass, ppo_controller.py:34,48): only the outputs are written, several workgroups per CU
+struct InferArgs {
+  NetArgs net[2];
+  int32_t which[2];     // blockIdx.y -> network index
+  const float *obs, *action, *log_std;
+  int64_t B;
+  int32_t A;
+  float *value, *mean, *logp;
+};
+
+template <int D, int KB0, int NO>
+__global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
+  constexpr int LDW0 = 32 * KB0 + 1;
+  constexpr int XT = 32 * KB0 * LDT;
+  __shared__ __align__(16) float sW0[64 * LDW0];
+  __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];
+  __shared__ __align__(16) float sWL[NO * 64];
+  __shared__ __align__(16) float sB[2 * 64 + 4];
+  __shared__ __align__(16) float sT[4 * XT];
+  const int net = P.which[blockIdx.y];
+  const NetArgs &a = P.net[net];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int K0 = a.dims[0];
+  const int64_t B = P.B;
+  const int A = P.A;
+  stage_weights<D, LDW0, NO, false>(a, sW0, sW1, nullptr, sWL, sB, tid);
+  float *sX = sT + wave * XT;
+  for (int e = lane; e < XT; e += 64) sX[e] = 0.f;
+  __syncthreads();
+
+  float var2[NO], logsig[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    var2[n] = 2.f; logsig[n] = 0.f;
+    if (net == 1 && P.logp && n < A) {
+      const float sigma = expf(P.log_std[n]);
+      var2[n] = 2.0f * (sigma * sigma);
+      logsig[n] = logf(sigma);
+    }
+  }
+  const int q64 = 64 / K0, m64 = 64 % K0;
+  const int ksteps0 = (K0 + 1) >> 1;
+  constexpr int XPF = 6;
+  const bool xpf = 32 * K0 <= 64 * XPF;
+  int xoff[XPF];
+  {
+    int rr = lane / K0, kk = lane % K0;
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) {
+      xoff[j] = kk * LDT + rr;
+      rr += q64; kk += m64;
+      if (kk >= K0) { kk -= K0; ++rr; }
+    }
+  }
+  float xr[XPF], p_act[NO];
+#pragma unroll
+  for (int j = 0; j < XPF; ++j) xr[j] = 0.f;
+#pragma unroll
+  for (int n = 0; n < NO; ++n) p_act[n] = 0.f;
+  const int nelem = 32 * K0;
+  const bool want_lp = net == 1 && P.logp != nullptr;
+  auto fetch = [&](int64_t strip) {
+    const int64_t row0 = strip << 5;
+    const int64_t row = row0 + r32;
+    const int64_t rowc = row < B ? row : B - 1;
+    if (xpf) {
+      const float *base = P.obs + row0 * K0;
+      const int64_t avail = (B - row0) * K0;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) {
+        const int e = lane + 64 * j;
+        xr[j] = (e < nelem && e < avail) ? base[e] : 0.f;
+      }
+    }
+    if (want_lp) {
+#pragma unroll
+      for (int n = 0; n < NO; ++n)
+        if (n < A) p_act[n] = P.action[rowc * A + n];
+    }
+  };
+  const int64_t nstrips = (B + 31) >> 5;
+  const int64_t sstride = (int64_t)gridDim.x * 4;
+  int64_t strip = (int64_t)blockIdx.x * 4 + wave;
+  if (strip < nstrips) fetch(strip);
+  for (; strip < nstrips; strip += sstride) {
+    const int64_t row0 = strip << 5;
+    const int64_t row = row0 + r32;
+    const bool valid = row < B;
+    if (xpf) {
+#pragma unroll
+      for (int j = 0; j < XPF; ++j)
+        if (lane + 64 * j < nelem) sX[xoff[j]] = xr[j];
+    } else {
+      const float *base = P.obs + row0 * K0;
+      const int64_t avail = (B - row0) * K0;
+      int rr = lane / K0, kk = lane % K0;
+      for (int e = lane; e < nelem; e += 64) {
+        sX[kk * LDT + rr] = e < avail ? base[e] : 0.f;
+        rr += q64; kk += m64;
+        if (kk >= K0) { kk -= K0; ++rr; }
+      }
+    }
+    float act[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) act[n] = p_act[n];
+    if (strip + sstride < nstrips) fetch(strip + sstride);
+    wave_lds_fence();
+    f32x16 h1[2], h2[2];
+    fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+    if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+    const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
+    float out[NO];
+    fwd_last<NO>(out, hl, sWL, sB + 128, half);
+    if (valid && half == 0) {
+      if (net == 0) {
+        P.value[row] = out[0];
+      } else {
+#pragma unroll
+        for (int n = 0; n < NO; ++n)
+          if (n < A) {
+            if (P.mean) P.mean[row * A + n] = out[n];
+            if (P.logp) {
+              const float d = act[n] - out[n];
+              P.logp[row * A + n] = ((-(d * d)) / var2[n] - logsig[n]) - LOG_SQRT_2PI;   // Normal.log_prob
+            }
+          }
+      }
+    }
+    wave_lds_fence();     // the next strip overwrites sX
+  }
+}
+
 // ---- second launch: sums the partial sets of every workgroup in a fixed order and writes
 // each parameter's gradient to its destination; one extra block finishes the scalars.
 struct GradDst {
@@ -880,6 +1035,53 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
   const int np_max = R.nparams[0] > R.nparams[1] ? R.nparams[0] : R.nparams[1];
   const int pblocks = (int)trl_cdiv(np_max, 16);
   hipLaunchKernelGGL(k_learn_reduce, dim3((unsigned)pblocks + 1, 2), dim3(256), 0, st, R, pblocks);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                     const float *obs, const float *action, int64_t B, int32_t A, float *value,
+                                     float *mean, float *logp, void *stream) {
+  const char *fn = "trl_ppo_forward_fused";
+  TRL_REQUIRE(obs, "%s: null obs", fn);
+  TRL_REQUIRE(B > 0 && B < (1ll << 36), "%s: B=%lld out of range", fn, (long long)B);
+  TRL_REQUIRE(value || mean || logp, "%s: no output requested", fn);
+  const bool want_actor = mean || logp;
+  TRL_REQUIRE(!value || critic, "%s: value requested without a critic", fn);
+  TRL_REQUIRE(!want_actor || actor, "%s: mean / logp requested without an actor", fn);
+  TRL_REQUIRE(!logp || (action && log_std), "%s: logp needs action and log_std", fn);
+  InferArgs P{};
+  int ny = 0, D = 0, K0 = 0;
+  if (value) {
+    int rc = fill_net(fn, critic, 1, &P.net[0]);
+    if (rc) return rc;
+    P.which[ny++] = 0;
+    D = critic->depth; K0 = critic->dims[0];
+  }
+  if (want_actor) {
+    TRL_REQUIRE(A >= 1 && A <= 4, "%s: action size %d not in [1, 4]", fn, A);
+    int rc = fill_net(fn, actor, A, &P.net[1]);
+    if (rc) return rc;
+    TRL_REQUIRE(P.net[1].dims[actor->depth] == A, "%s: the actor's fan-out is not the action size %d", fn, A);
+    TRL_REQUIRE(!value || (actor->depth == D && actor->dims[0] == K0),
+                "%s: critic and actor must have the same depth and observation size", fn);
+    P.which[ny++] = 1;
+    D = actor->depth; K0 = actor->dims[0];
+  }
+  P.obs = obs; P.action = action; P.log_std = log_std; P.B = B; P.A = want_actor ? A : 1;
+  P.value = value; P.mean = mean; P.logp = logp;
+  const int64_t need = trl_cdiv(trl_cdiv(B, 32), 4);
+  const int64_t cap = 768 / ny;      // ~3 workgroups per CU over the launch
+  const dim3 grid((unsigned)(need < cap ? need : cap), (unsigned)ny), block(256);
+  const int KB0 = K0 <= 32 ? 1 : 2, NOv = (!want_actor || A <= 1) ? 1 : (A <= 2 ? 2 : 4);
+  hipStream_t st = (hipStream_t)stream;
+#define TRL_INFER_CASE(d, kb, no) \
+  if (D == d && KB0 == kb && NOv == no) hipLaunchKernelGGL((k_ac_infer<d, kb, no>), grid, block, 0, st, P);
+  TRL_INFER_CASE(2, 1, 1) TRL_INFER_CASE(2, 1, 2) TRL_INFER_CASE(2, 1, 4)
+  TRL_INFER_CASE(2, 2, 1) TRL_INFER_CASE(2, 2, 2) TRL_INFER_CASE(2, 2, 4)
+  TRL_INFER_CASE(3, 1, 1) TRL_INFER_CASE(3, 1, 2) TRL_INFER_CASE(3, 1, 4)
+  TRL_INFER_CASE(3, 2, 1) TRL_INFER_CASE(3, 2, 2) TRL_INFER_CASE(3, 2, 4)
+#undef TRL_INFER_CASE
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
 }

@@ -524,6 +524,28 @@ class FusedPpoLearn:
     return obs.is_cuda and obs.dim() == 2 and obs.dtype == torch.float32 and obs.shape[0] >= self.MIN_BATCH \
         and obs.shape[1] == self.K0
 
+  def forward(self, obs, action=None, want_value=True, want_mean=True):
+    """No-grad forward over obs [B, fan-in] writing only the outputs (trl_ppo_forward_fused):
+    returns (value [B] | None, mean [B, A] | None, logp [B, A] | None); logp =
+    Normal(mean, exp(log_std)).log_prob(action) per dimension when `action` is given."""
+    C = self._C
+    obs = _f32c(obs, 'obs')
+    B, dev = obs.shape[0], obs.device
+    if action is not None:
+      action = _f32c(action, 'action')
+      if action.numel() != B * self.A:
+        raise ValueError('ppo_forward_fused: action must be [B, %d]' % self.A)
+    if self._ptr_key() != self._key:
+      self._bind()
+    value = torch.empty(B, dtype=torch.float32, device=dev) if want_value else None
+    mean = torch.empty((B, self.A), dtype=torch.float32, device=dev) if want_mean else None
+    logp = torch.empty((B, self.A), dtype=torch.float32, device=dev) if action is not None else None
+    with torch.cuda.device(dev):
+      _lib.check(_lib.lib().trl_ppo_forward_fused(
+          C.byref(self.descs[0]), C.byref(self.descs[1]), self.log_std.data_ptr(), obs.data_ptr(), _lib.ptr(action),
+          B, self.A, _lib.ptr(value), _lib.ptr(mean), _lib.ptr(logp), _lib.stream_ptr(dev)))
+    return value, mean, logp
+
   def __call__(self, obs, action, returns, old_logp, adv, clip, alpha, beta, adam=None):
     """adam: an optim.FlatAdam over the flat buffers holding these parameters -> clip + Adam run
     inside the reduce launch (its step count is advanced here); None -> gradients only."""
