@@ -37,6 +37,7 @@ from torchrl_amd.contrib.controllers import PPOController, DDPGController, DQNCo
 from torchrl_amd.utils.storage import TensorTupleDataset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (MI355X_MICROARCH.md, matrix cores)
 
 
 def parse():
@@ -161,7 +162,9 @@ def make_rollout(T, N, obs_size, act_size, dev, seed):
 def bench_ppo(args, rank, world, dev):
   T, N, obs_size, act_size = args.T, args.N, 3, 1
   hidden = tuple(int(h) for h in args.hidden.split(','))
-  B = args.minibatch or 65536
+  # 32 minibatches per epoch (T*N / 32 = 262,144 at the default shape), the usual PPO split of a rollout;
+  # --minibatch overrides (65,536 = 128 minibatches per epoch was the earlier default)
+  B = args.minibatch or max(1, (T * N) // 32)
   steps = args.steps if args.steps is not None else 5
   warmup = args.warmup if args.warmup is not None else 1
   torch.manual_seed(0)
@@ -171,7 +174,7 @@ def bench_ppo(args, rank, world, dev):
   obs, action, reward, done, last_next_obs = make_rollout(T, N, obs_size, act_size, dev, 1234 + rank)
   last_done = done[-1]
   n = T * N
-  phase = {}
+  phase, keep = {}, {}
 
   def step():
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -184,6 +187,7 @@ def bench_ppo(args, rank, world, dev):
     act_em = action.transpose(0, 1).reshape(n, act_size)
     logp_em = logp.transpose(0, 1).reshape(n, act_size)
     ret_em, adv_em = returns.reshape(n, 1), adv.reshape(n, 1)
+    keep.update(obs_em=obs_em, act_em=act_em, logp_em=logp_em, ret_em=ret_em, adv_em=adv_em)
     e1.record()
     trace('compute_return done')
     for _ in range(args.epochs):
@@ -253,6 +257,24 @@ def bench_ppo(args, rank, world, dev):
       'roofline': roof,
   }
   res.update(extra)
+  if ctl._fused is not None:
+    # the whole-step kernel pair alone (gradients only), graph-timed like the GAE kernel; FLOPs are the
+    # networks' own (no padding): forward, weight gradients, and input gradients of the hidden layers
+    f = ctl._fused
+    sl = slice(0, min(B, n))
+    a_ = tuple(keep[k][sl].contiguous() for k in ('obs_em', 'act_em', 'ret_em', 'logp_em', 'adv_em'))
+    us_l = kernel_time_us(lambda: f(*a_, 0.2, 0.5, 1e-3), max(10, args.kernel_iters // 2))
+    flops = 0
+    for lin in (f.critic_lin, f.actor_lin):
+      for i, m in enumerate(lin):
+        flops += (4 if i == 0 else 6) * m.in_features * m.out_features
+    flops *= a_[0].shape[0]
+    tf = flops / (us_l * 1e-6) / 1e12
+    res['learn_kernel'] = {'kernel': 'k_ac_learn+k_learn_reduce', 'bound': 'mfma', 'achieved': round(tf, 1),
+                           'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                           'us_per_launch': round(us_l, 2), 'flops_per_launch': int(flops),
+                           'note': 'forward + PPO loss + backward of critic and actor over one minibatch of %d '
+                                   '(exact f32 MFMA); %d FLOP per sample' % (a_[0].shape[0], flops // a_[0].shape[0])}
   return res, dict(T=T, hidden=hidden, B=B, epochs=args.epochs)
 
 
