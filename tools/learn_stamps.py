@@ -38,3 +38,12 @@ print('first entry -> last exit over all waves: %.2f us' % ((rt[:, 3].max() - rt
 print('entry spread: %.2f us' % ((rt[:, 0].max() - rt[:, 0].min()) / 100.0))
 dc, dr = clk[:, 2] - clk[:, 1], rt[:, 2] - rt[:, 1]
 print('loop clock %.2f GHz' % (np.median(dc / dr) * 0.1))
+off = 2 * 128 * pstride * 4 + 2 * 128 * 4 * 64
+ph = ws[off:off + 2 * nwg * 4 * 128].cpu().numpy().view(np.uint64)
+ph = ph.reshape(2 * nwg * 4, 16).astype(np.float64)
+nst = (B + 31) // 32 / (nwg * 4)
+names = {5: 'loop top -> inputs in registers', 6: 'x tile write + fence', 7: 'layer 0 forward + relu', 8: 'layer 1 forward + relu',
+         0: 'last layer forward', 1: 'loss + last layer backward', 2: 'layer 1 backward (tiles, dW1, g0, mask)',
+         9: 'layer 0 backward: db0, tile, fence', 3: 'layer 0 backward: dW0 MFMAs'}
+for k in (5, 6, 7, 8, 0, 1, 2, 9, 3):
+  print('  phase %-42s %8.0f cycles per strip' % (names[k], np.median(ph[:, k]) / nst))

@@ -86,8 +86,27 @@ struct LearnArgs {
       sp[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                                               \
     }                                                                                                   \
   } while (0)
+// in-loop phase clocks: PH(k) adds the shader cycles since the previous PH to phase k
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(k)                                                   \
+  do {                                                          \
+    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    ph_acc[k] += now - ph_t;                                    \
+    ph_t = now;                                                 \
+  } while (0)
+#define PH_OUT                                                                                          \
+  do {                                                                                                  \
+    if (lane == 0) {                                                                                    \
+      unsigned long long *sp = (unsigned long long *)(P.ws + 2ll * 128 * P.pstride) + 2 * 128 * 4 * 8 + \
+                               (((int64_t)net * gridDim.x + blockIdx.x) * 4 + wave) * 16;               \
+      for (int k = 0; k < 12; ++k) sp[k] = ph_acc[k];                                                    \
+    }                                                                                                   \
+  } while (0)
 #else
 #define STAMP(i)
+#define PH_DECL
+#define PH(k)
+#define PH_OUT
 #endif
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -249,10 +268,11 @@ __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, floa
 
 // D = depth (2: in -> H -> out, 3: in -> H -> H -> out); KB0 = 32-blocks of the fan-in;
 // NO = padded fan-out of the last layer (actual fan-outs <= NO)
-template <int D, int KB0, int NO>
+// XP: the strip's observations are prefetched into registers (fan-in <= 12)
+template <int D, int KB0, int NO, bool XP>
 __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   constexpr int LDW0 = 32 * KB0 + 1;
-  constexpr int XT = 32 * KB0 * LDT;                 // floats of the x tile
+  constexpr int XT = 32 * KB0 * LDT + 4;             // floats of the x tile (+ a dummy slot for idle prefetch lanes)
   constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0);   // per-wave scratch
   constexpr int WTP = (WT + 3) & ~3;
   __shared__ __align__(16) float sW0[64 * LDW0];
@@ -328,63 +348,71 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int q64 = 64 / K0, m64 = 64 % K0;
   const int ksteps0 = (K0 + 1) >> 1;
 
-  // ---- inputs of a strip are fetched one strip ahead, into registers (nothing else would
-  // hide the HBM latency): XPF observation elements per lane (fan-in <= 12; wider observations
-  // are read in place) and the per-sample loss inputs (both lane halves hold their row's values)
+  // ---- inputs of a strip are fetched one strip ahead, into registers (nothing else would hide
+  // the HBM latency): XPF observation elements per lane (XP: fan-in <= 12; wider observations are
+  // read in place) and the per-sample loss inputs (both lane halves hold their row's values).
+  // The fetch is branch-free -- clamped addresses, idle lanes write a dummy LDS slot -- so that
+  // the loads of strip i+1 stay in flight across strip i (a load under a branch makes the
+  // compiler drain the vector-memory counter at the next join).
   constexpr int XPF = 6;
-  const bool xpf = 32 * K0 <= 64 * XPF;
+  const int nelem = 32 * K0;
   int xoff[XPF];
   {
     int rr = lane / K0, kk = lane % K0;
 #pragma unroll
     for (int j = 0; j < XPF; ++j) {
-      xoff[j] = kk * LDT + rr;
+      xoff[j] = lane + 64 * j < nelem ? kk * LDT + rr : XT - 4;
       rr += q64; kk += m64;
       if (kk >= K0) { kk -= K0; ++rr; }
     }
   }
-  float xr[XPF], p_ret = 0.f, p_ad = 0.f, p_act[NO], p_olp[NO];
+  // slot 0: returns (critic) / advantages (actor); action and old log-prob per dimension (the
+  // critic and the padded dimensions re-read slot 0's array: always a valid address)
+  const float *in0 = net == 0 ? P.returns : P.adv;
+  const float *in_act[NO], *in_olp[NO];
+  const int astr = net == 0 ? 1 : A;
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    in_act[n] = net == 0 ? in0 : P.action + (n < A ? n : 0);
+    in_olp[n] = net == 0 ? in0 : P.old_logp + (n < A ? n : 0);
+  }
+  float xr[XPF], p_in0 = 0.f, p_act[NO], p_olp[NO];
 #pragma unroll
   for (int j = 0; j < XPF; ++j) xr[j] = 0.f;
-#pragma unroll
-  for (int n = 0; n < NO; ++n) p_act[n] = p_olp[n] = 0.f;
-  const int nelem = 32 * K0;
+  const int64_t nstrips = (B + 31) >> 5;
   auto fetch = [&](int64_t strip) {
+    strip = strip < nstrips ? strip : nstrips - 1;
     const int64_t row0 = strip << 5;
     const int64_t row = row0 + r32;
     const int64_t rowc = row < B ? row : B - 1;
-    if (xpf) {
+    if (XP) {
       const float *base = P.obs + row0 * K0;
-      const int64_t avail = (B - row0) * K0;          // elements before the end of obs
+      const int64_t avail = (B - row0) * K0;          // elements before the end of obs (>= K0)
+      const int last = (int)(avail < nelem ? avail : nelem) - 1;
 #pragma unroll
       for (int j = 0; j < XPF; ++j) {
         const int e = lane + 64 * j;
-        xr[j] = (e < nelem && e < avail) ? base[e] : 0.f;
+        xr[j] = base[e < last ? e : last];
       }
     }
-    if (net == 0) {
-      p_ret = P.returns[rowc];
-    } else {
-      p_ad = P.adv[rowc];
+    p_in0 = in0[rowc];
 #pragma unroll
-      for (int n = 0; n < NO; ++n)
-        if (n < A) { p_act[n] = P.action[rowc * A + n]; p_olp[n] = P.old_logp[rowc * A + n]; }
-    }
+    for (int n = 0; n < NO; ++n) { p_act[n] = in_act[n][rowc * astr]; p_olp[n] = in_olp[n][rowc * astr]; }
   };
 
-  const int64_t nstrips = (B + 31) >> 5;
   const int64_t sstride = (int64_t)gridDim.x * 4;
   int64_t strip = (int64_t)blockIdx.x * 4 + wave;
-  if (strip < nstrips) fetch(strip);
+  fetch(strip);
+  PH_DECL
   for (; strip < nstrips; strip += sstride) {
     const int64_t row0 = strip << 5;
     const bool valid = row0 + r32 < B;
+    PH(5);
 
     // ---- x^T of the strip -> sX[k][row] (the strip's rows are contiguous in obs)
-    if (xpf) {
+    if (XP) {
 #pragma unroll
-      for (int j = 0; j < XPF; ++j)
-        if (lane + 64 * j < nelem) sX[xoff[j]] = xr[j];
+      for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
     } else {
       const float *base = P.obs + row0 * K0;
       const int64_t avail = (B - row0) * K0;
@@ -395,21 +423,25 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
         if (kk >= K0) { kk -= K0; ++rr; }
       }
     }
-    const float ret = p_ret, ad = p_ad;
+    const float ret = p_in0, ad = p_in0;
     float act[NO], olp[NO];
 #pragma unroll
     for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
-    if (strip + sstride < nstrips) fetch(strip + sstride);
+    fetch(strip + sstride);
     wave_lds_fence();
+    PH(6);
 
     // ---- forward: h1, (h2), out
     f32x16 h1[2], h2[2];
     fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+    PH(7);
     if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+    PH(8);
     const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
     float out[NO];
     fwd_last<NO>(out, hl, sWL, sB + 128, half);
 
+    PH(0);
     // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
     float gout[NO];
     const bool count = valid && half == 0;    // each row's loss terms are summed once
@@ -470,6 +502,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     for (int n = 0; n < NO; ++n)
       if (half == 0) dbL[n] += gout[n];
 
+    PH(1);
     // ---- layer 1 backward (D == 3): dW1 += g h1^T (rows through LDS), g <- (W1^T g) * (h1 > 0)
     if (D == 3) {
 #pragma unroll
@@ -534,6 +567,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
         for (int r = 0; r < 16; ++r) g[kb][r] = h1[kb][r] > 0.f ? t[kb][r] : 0.f;
     }
 
+    PH(2);
     // ---- layer 0 backward: dW0 += g x^T
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -541,6 +575,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       for (int r = 0; r < 16; ++r) db0[nb][r] += g[nb][r];
     put_tile(sG, g, half, r32);
     wave_lds_fence();
+    PH(9);
     {
       const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
       float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), xv[KB0];
@@ -570,7 +605,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       }
     }
     wave_lds_fence();     // the next strip overwrites sX / sG
+    PH(3);
   }
+  PH_OUT;
 
   STAMP(2);
   // =========================================================================== partials out
@@ -692,10 +729,10 @@ struct InferArgs {
   float *value, *mean, *logp;
 };
 
-template <int D, int KB0, int NO>
+template <int D, int KB0, int NO, bool XP>
 __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
   constexpr int LDW0 = 32 * KB0 + 1;
-  constexpr int XT = 32 * KB0 * LDT;
+  constexpr int XT = 32 * KB0 * LDT + 4;
   __shared__ __align__(16) float sW0[64 * LDW0];
   __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];
   __shared__ __align__(16) float sWL[NO * 64];
@@ -724,56 +761,55 @@ __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
   }
   const int q64 = 64 / K0, m64 = 64 % K0;
   const int ksteps0 = (K0 + 1) >> 1;
-  constexpr int XPF = 6;
-  const bool xpf = 32 * K0 <= 64 * XPF;
+  constexpr int XPF = 6;          // branch-free one-strip-ahead fetch, as in k_ac_learn
+  const int nelem = 32 * K0;
   int xoff[XPF];
   {
     int rr = lane / K0, kk = lane % K0;
 #pragma unroll
     for (int j = 0; j < XPF; ++j) {
-      xoff[j] = kk * LDT + rr;
+      xoff[j] = lane + 64 * j < nelem ? kk * LDT + rr : XT - 4;
       rr += q64; kk += m64;
       if (kk >= K0) { kk -= K0; ++rr; }
     }
   }
+  const bool want_lp = net == 1 && P.logp != nullptr;
+  const float *in_act[NO];
+  const int astr = want_lp ? A : 0;
+#pragma unroll
+  for (int n = 0; n < NO; ++n) in_act[n] = want_lp ? P.action + (n < A ? n : 0) : P.obs;
   float xr[XPF], p_act[NO];
 #pragma unroll
   for (int j = 0; j < XPF; ++j) xr[j] = 0.f;
-#pragma unroll
-  for (int n = 0; n < NO; ++n) p_act[n] = 0.f;
-  const int nelem = 32 * K0;
-  const bool want_lp = net == 1 && P.logp != nullptr;
+  const int64_t nstrips = (B + 31) >> 5;
   auto fetch = [&](int64_t strip) {
+    strip = strip < nstrips ? strip : nstrips - 1;
     const int64_t row0 = strip << 5;
     const int64_t row = row0 + r32;
     const int64_t rowc = row < B ? row : B - 1;
-    if (xpf) {
+    if (XP) {
       const float *base = P.obs + row0 * K0;
       const int64_t avail = (B - row0) * K0;
+      const int last = (int)(avail < nelem ? avail : nelem) - 1;
 #pragma unroll
       for (int j = 0; j < XPF; ++j) {
         const int e = lane + 64 * j;
-        xr[j] = (e < nelem && e < avail) ? base[e] : 0.f;
+        xr[j] = base[e < last ? e : last];
       }
     }
-    if (want_lp) {
 #pragma unroll
-      for (int n = 0; n < NO; ++n)
-        if (n < A) p_act[n] = P.action[rowc * A + n];
-    }
+    for (int n = 0; n < NO; ++n) p_act[n] = in_act[n][rowc * astr];
   };
-  const int64_t nstrips = (B + 31) >> 5;
   const int64_t sstride = (int64_t)gridDim.x * 4;
   int64_t strip = (int64_t)blockIdx.x * 4 + wave;
-  if (strip < nstrips) fetch(strip);
+  fetch(strip);
   for (; strip < nstrips; strip += sstride) {
     const int64_t row0 = strip << 5;
     const int64_t row = row0 + r32;
     const bool valid = row < B;
-    if (xpf) {
+    if (XP) {
 #pragma unroll
-      for (int j = 0; j < XPF; ++j)
-        if (lane + 64 * j < nelem) sX[xoff[j]] = xr[j];
+      for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
     } else {
       const float *base = P.obs + row0 * K0;
       const int64_t avail = (B - row0) * K0;
@@ -787,7 +823,7 @@ __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
     float act[NO];
 #pragma unroll
     for (int n = 0; n < NO; ++n) act[n] = p_act[n];
-    if (strip + sstride < nstrips) fetch(strip + sstride);
+    fetch(strip + sstride);
     wave_lds_fence();
     f32x16 h1[2], h2[2];
     fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
@@ -1024,8 +1060,12 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)nwg, 2), block(256);
   const int D = critic->depth, KB0 = critic->dims[0] <= 32 ? 1 : 2, NOv = A <= 1 ? 1 : (A <= 2 ? 2 : 4);
-#define TRL_LEARN_CASE(d, kb, no) \
-  if (D == d && KB0 == kb && NOv == no) hipLaunchKernelGGL((k_ac_learn<d, kb, no>), grid, block, 0, st, P);
+  const bool xp = critic->dims[0] <= 12;
+#define TRL_LEARN_CASE(d, kb, no)                                                                  \
+  if (D == d && KB0 == kb && NOv == no) {                                                          \
+    if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_learn<d, kb, no, kb == 1>), grid, block, 0, st, P); \
+    else hipLaunchKernelGGL((k_ac_learn<d, kb, no, false>), grid, block, 0, st, P);               \
+  }
   TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
   TRL_LEARN_CASE(2, 2, 1) TRL_LEARN_CASE(2, 2, 2) TRL_LEARN_CASE(2, 2, 4)
   TRL_LEARN_CASE(3, 1, 1) TRL_LEARN_CASE(3, 1, 2)
@@ -1075,8 +1115,12 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
   const dim3 grid((unsigned)(need < cap ? need : cap), (unsigned)ny), block(256);
   const int KB0 = K0 <= 32 ? 1 : 2, NOv = (!want_actor || A <= 1) ? 1 : (A <= 2 ? 2 : 4);
   hipStream_t st = (hipStream_t)stream;
-#define TRL_INFER_CASE(d, kb, no) \
-  if (D == d && KB0 == kb && NOv == no) hipLaunchKernelGGL((k_ac_infer<d, kb, no>), grid, block, 0, st, P);
+  const bool xp = K0 <= 12;
+#define TRL_INFER_CASE(d, kb, no)                                                                  \
+  if (D == d && KB0 == kb && NOv == no) {                                                          \
+    if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_infer<d, kb, no, kb == 1>), grid, block, 0, st, P); \
+    else hipLaunchKernelGGL((k_ac_infer<d, kb, no, false>), grid, block, 0, st, P);               \
+  }
   TRL_INFER_CASE(2, 1, 1) TRL_INFER_CASE(2, 1, 2) TRL_INFER_CASE(2, 1, 4)
   TRL_INFER_CASE(2, 2, 1) TRL_INFER_CASE(2, 2, 2) TRL_INFER_CASE(2, 2, 4)
   TRL_INFER_CASE(3, 1, 1) TRL_INFER_CASE(3, 1, 2) TRL_INFER_CASE(3, 1, 4)
