@@ -152,6 +152,17 @@ __device__ __forceinline__ void put_tile(float *tile, const f32x16 (&v)[2], int 
     for (int r = 0; r < 16; ++r) tile[(nb * 32 + feat(r, half)) * LDT + r32] = v[nb][r];
 }
 
+// sum of the 32 floats of one tile row (16 B aligned), four interleaved partial sums, fixed order
+__device__ __forceinline__ float row_sum32(const float *row) {
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = ld4(row + 4 * i);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s0 += v[i].x; s1 += v[i].y; s2 += v[i].z; s3 += v[i].w; }
+  return (s0 + s1) + (s2 + s3);
+}
+
 // ---- forward pieces, shared by the learner kernel and the inference kernel
 // layer 0: h1^T = relu(W0 x^T + b0); x^T from the strip's LDS tile, k walked in natural order
 template <int LDW0>
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // ---- per-wave persistent state
   f32x16 accW0[2][KB0];
   f32x16 accW1[2][2];
-  f32x16 db0[2], db1[2];
+  float vdb0 = 0.f, vdb1 = 0.f;     // bias gradients of feature `lane`: row sums of the g tiles
   f32x16 dWL[NO][2];
   float dbL[NO];
 #pragma unroll
@@ -318,8 +329,6 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accW1[nb][kb][r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { db0[nb][r] = 0.f; db1[nb][r] = 0.f; }
   }
 #pragma unroll
   for (int n = 0; n < NO; ++n) {
@@ -505,13 +514,10 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     PH(1);
     // ---- layer 1 backward (D == 3): dW1 += g h1^T (rows through LDS), g <- (W1^T g) * (h1 > 0)
     if (D == 3) {
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) db1[nb][r] += g[nb][r];
       put_tile(sG, g, half, r32);
       put_tile(sH, h1, half, r32);
       wave_lds_fence();
+      vdb1 += row_sum32(sG + lane * LDT);     // db1[lane] += sum over the strip's rows of g[lane][row]
       // rows in the order (j, half, i) -> row 8j + 4half + i: a lane's four steps are one 16 B read
       const float *ga = sG + r32 * LDT + 4 * half, *ha = sH + r32 * LDT + 4 * half;
       {
@@ -569,12 +575,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 
     PH(2);
     // ---- layer 0 backward: dW0 += g x^T
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) db0[nb][r] += g[nb][r];
     put_tile(sG, g, half, r32);
     wave_lds_fence();
+    vdb0 += row_sum32(sG + lane * LDT);
     PH(9);
     {
       const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
@@ -614,24 +617,12 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // Everything below runs once per workgroup and re-uses the per-wave scratch regions of sT.
   float *part = P.ws + ((int64_t)net * gridDim.x + blockIdx.x) * P.pstride;
 
-  // per-lane partial vectors (db0, db1, dWL[n]) -> per-feature sums over the wave's 32 rows:
-  // transposed through the wave's own tile
-  float vec_db0, vec_db1 = 0.f, vec_wl[NO];
+  // per-lane partial vectors dWL[n] -> per-feature sums over the wave's 32 rows: transposed
+  // through the wave's own tile (the bias gradients vdb0 / vdb1 are per feature already)
+  const float vec_db0 = vdb0, vec_db1 = vdb1;
+  float vec_wl[NO];
   {
-    put_tile(sG, db0, half, r32);
-    wave_lds_fence();
-    float s = 0.f;
-    for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
-    vec_db0 = s;
-    wave_lds_fence();
-    if (D == 3) {
-      put_tile(sG, db1, half, r32);
-      wave_lds_fence();
-      s = 0.f;
-      for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
-      vec_db1 = s;
-      wave_lds_fence();
-    }
+    float s;
 #pragma unroll
     for (int n = 0; n < NO; ++n) {
       put_tile(sG, dWL[n], half, r32);
