@@ -36,18 +36,36 @@ inline uint32_t twist(uint32_t u, uint32_t v) {
   return (((u & UMASK) | (v & LMASK)) >> 1) ^ ((v & 1u) ? MATRIX_A : 0u);
 }
 
-// One state regeneration (624 words).  Word j depends on words j+1 and j+397 (mod 624), i.e. on
-// values at least 227 positions away from anything written in the same pass, so the loops are
-// vectorisable; the AVX2 clone is picked at load time where the host has it.  A replay sample
-// from a 1 M-row buffer skips ~1600 of these, which is the whole cost of the lock-step sampler.
-__attribute__((target_clones("avx2", "default"))) void mt_regen(uint32_t *__restrict__ s) {
-  uint32_t t[MT_N + 1];
-  memcpy(t, s, MT_N * sizeof(uint32_t));
+// One state regeneration (624 words), out of place.  Word j depends on the old words j, j+1 and
+// either the old word j+397 or the NEW word j-227, i.e. on values at least 227 positions away from
+// anything written in the same sweep, so the loops vectorise; the AVX-512 / AVX2 clone is picked
+// at load time where the host has it.  A replay sample from a 1 M-row buffer skips ~1600 of
+// these, which is the whole cost of the lock-step sampler.
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void mt_regen_oop(const uint32_t *__restrict__ t, uint32_t *__restrict__ s) {
   for (int j = 0; j < MT_N - MT_M; ++j) s[j] = t[j + MT_M] ^ twist(t[j], t[j + 1]);
-  // second part reads words written by the first part, 227 behind: do it in two sweeps of < 227
+  // second part reads words written by the first part, 227 behind: two sweeps of < 227
   for (int j = MT_N - MT_M; j < 2 * (MT_N - MT_M); ++j) s[j] = s[j + MT_M - MT_N] ^ twist(t[j], t[j + 1]);
   for (int j = 2 * (MT_N - MT_M); j < MT_N - 1; ++j) s[j] = s[j + MT_M - MT_N] ^ twist(t[j], t[j + 1]);
   s[MT_N - 1] = s[MT_M - 1] ^ twist(t[MT_N - 1], s[0]);
+}
+
+void mt_regen(uint32_t *s) {
+  uint32_t t[MT_N];
+  memcpy(t, s, sizeof(t));
+  mt_regen_oop(t, s);
+}
+
+// k regenerations in a row (the skipped part of a sample): ping-pong between the state and a
+// scratch copy, no copies in between
+void mt_regen_many(uint32_t *s, int64_t k) {
+  uint32_t t[MT_N];
+  while (k >= 2) {
+    mt_regen_oop(s, t);
+    mt_regen_oop(t, s);
+    k -= 2;
+  }
+  if (k == 1) mt_regen(s);
 }
 
 struct Mt {
@@ -68,18 +86,20 @@ struct Mt {
     return y;
   }
   void skip(int64_t k) {
-    while (k > 0) {
-      const int64_t plain = left - 1;  // draws that do not regenerate
-      if (k <= plain) {
-        left -= (int32_t)k;
-        next += (int32_t)k;
-        return;
-      }
-      k -= plain;
-      regen();  // the draw that finds left == 1
-      next = 1;
-      k -= 1;
+    const int64_t plain = left - 1;  // draws that do not regenerate
+    if (k <= plain) {
+      left -= (int32_t)k;
+      next += (int32_t)k;
+      return;
     }
+    k -= plain;                      // the next draw finds left == 1 and regenerates
+    // r >= 1 regenerations, each good for 624 draws (the one that triggers it included); with c in
+    // [1, 624] draws taken from the newest state the position is left = 625 - c, next = c
+    const int64_t r = (k + MT_N - 1) / MT_N;
+    const int64_t c = k - (r - 1) * MT_N;
+    mt_regen_many(s, r);
+    left = (int32_t)(MT_N + 1 - c);
+    next = (int32_t)c;
   }
 };
 
