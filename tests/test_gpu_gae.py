@@ -71,6 +71,26 @@ def test_masked_mode_vs_oracle():
   np.testing.assert_array_equal(got_r, ref_r)
 
 
+@pytest.mark.parametrize('T,N', [(5, 16), (128, 16), (129, 64), (300, 1000), (2048, 48), (64, 8192), (263, 16388),
+                                 (2048, 4096)])
+def test_masked_mode_pipelined_kernel_bitwise(T, N):
+  """Masked extension on the pipelined kernel (N % 4 == 0: done rides the LDS ring as a third
+  plane) vs the oracle's definition, both output layouts; fractional done values included."""
+  rs = np.random.RandomState(T + 7 * N)
+  reward, value = rs.randn(T, N).astype(np.float32), rs.randn(T, N).astype(np.float32)
+  boot = rs.randn(N).astype(np.float32)
+  done = (rs.rand(T, N) < 0.05).astype(np.float32)
+  done[rs.rand(T, N) < 0.01] = 0.25
+  exp_r, exp_a = gae_oracle.gae_numpy(reward, value, boot, 0.99, 0.95, done=done, masked=True)
+  d = torch.from_numpy(done).to(DEV)
+  got_r, got_a = _run(reward, value, boot, 0.99, 0.95, done=d, masked=True)
+  np.testing.assert_array_equal(got_r, exp_r)
+  np.testing.assert_array_equal(got_a, exp_a)
+  nt_r, nt_a = _run(reward, value, boot, 0.99, 0.95, done=d, masked=True, env_major_out=True)
+  np.testing.assert_array_equal(nt_r, exp_r.T)
+  np.testing.assert_array_equal(nt_a, exp_a.T)
+
+
 def test_linearity_property_full_size():
   """Size-independent check at full size: with lambda = 1 and V = 0 the return is the plain
   discounted sum, so returns(r1 + r2) ~= returns(r1) + returns(r2) and a single impulse at

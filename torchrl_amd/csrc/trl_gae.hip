@@ -119,9 +119,14 @@ __global__ __launch_bounds__(256) void k_gae_tiled(const float *__restrict__ rew
 // LDS-DMA visibility rule (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the
 // wait that retires it"): the DMA waves wait for tile s+1 at the END of stage s, before the
 // barrier; the workers read it in stage s+1.
-template <int E, int PF>
+// MASKED (extension): a third plane, done, rides the same ring; the workers fold (1 - done) into
+// delta and the chain wave reads the tile's done values straight from the raw ring (the slot of
+// the tile being scanned is the one kept alive as the next tile's halo):
+//   delta = (r + (gamma * v[t+1]) * (1 - d)) - v;   gae = delta + (gamma_lambda * (1 - d)) * gae
+template <int E, int PF, bool MASKED>
 __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ reward,
                                                   const float *__restrict__ value,
+                                                  const float *__restrict__ done,
                                                   const float *__restrict__ bootstrap, int T, int N,
                                                   float gamma, float gl, int out_nt, int ngroups,
                                                   float *__restrict__ returns,
@@ -140,10 +145,13 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
   constexpr int NS = 3;             // scan ring: staged / being scanned / being written out
   constexpr int NR = PF + 2;        // raw ring: PF in flight + being read + halo of the previous tile
   constexpr int RPI = 256 / E;      // rows one 1 KiB DMA instruction covers
+  constexpr int NP = MASKED ? 3 : 2;                // raw planes per tile: reward, value(, done)
+  constexpr int SLOT = NP * PLANE;
+  constexpr int LPT = 4 * NP;                       // loads per tile per DMA wave
   // one array: see cdna_hip_programming.md on a second __shared__ object beside a DMA ring
-  __shared__ __attribute__((aligned(16))) float lds[NR * 2 * PLANE + NS * (E * TTP + TT * LD)];
-  float *s_raw = lds;                               // [NR][2][PLANE]  (reward plane, value plane)
-  float *s_d = lds + NR * 2 * PLANE;                // [NS][E][TTP]    delta -> gae in place
+  __shared__ __attribute__((aligned(16))) float lds[NR * SLOT + NS * (E * TTP + TT * LD)];
+  float *s_raw = lds;                               // [NR][NP][PLANE]  (reward plane, value plane, done plane)
+  float *s_d = lds + NR * SLOT;                     // [NS][E][TTP]    delta -> gae in place
   float *s_v = s_d + NS * E * TTP;                  // [NS][TT][LD]
 
   // XCD-aware group order: blocks b and b + 8 share an XCD (its L2), so give each XCD a
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
     auto issue = [&](int j) {
       const int jc = j < ntiles ? j : ntiles - 1;
       const int lo = t_lo(jc), hi = t_hi(jc);
-      float *slot = s_raw + (j % NR) * 2 * PLANE;
+      float *slot = s_raw + (j % NR) * SLOT;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ins = dw * 4 + i;
@@ -181,27 +189,26 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(value + g),
                                          (__attribute__((address_space(3))) void *)(slot + PLANE + ins * 256), 16,
                                          0, 0);
+        if (MASKED)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(done + g),
+                                           (__attribute__((address_space(3))) void *)(slot + 2 * PLANE + ins * 256),
+                                           16, 0, 0);
       }
     };
+    // all but the PF - 1 youngest tiles of this wave have landed
+    auto wait_tile = [&]() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (PF - 1)) : "memory"); };
+    static_assert(LPT * (PF - 1) <= 63, "vmcnt is a 6-bit counter");
     static_assert(PF >= 1 && PF <= 5, "prefetch depth");
 #pragma unroll
     for (int j = 0; j < PF; ++j)
       if (!(dbg & 8)) issue(j);
-    // tile 0 landed (8 loads per tile per wave; PF - 1 younger tiles may stay in flight)
-    if (PF == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (PF == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    if (PF == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    if (PF == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    if (PF == 5) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    // tile 0 landed (LPT loads per tile per wave; PF - 1 younger tiles may stay in flight)
+    wait_tile();
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < nstages; ++s) {
       if (!(dbg & 8)) issue(s + PF);
       // tile s + 1 landed; tiles s+2 .. s+PF stay in flight across the barrier
-      if (PF == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (PF == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      if (PF == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      if (PF == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      if (PF == 5) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      wait_tile();
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain before the LDS is released
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
     for (int s = 0; s < nstages; ++s) {
       if (s < ntiles && !(dbg & 4)) {   // ---- stage tile s: delta and v into the padded scan buffers
         const int lo = t_lo(s), rows = t_hi(s) - lo;
-        const float *raw_r = s_raw + (s % NR) * 2 * PLANE, *raw_v = raw_r + PLANE;
-        const float *halo = s_raw + ((s + NR - 1) % NR) * 2 * PLANE + PLANE;   // tile s-1, row 0
+        const float *raw_r = s_raw + (s % NR) * SLOT, *raw_v = raw_r + PLANE, *raw_m = raw_r + 2 * PLANE;
+        const float *halo = s_raw + ((s + NR - 1) % NR) * SLOT + PLANE;   // tile s-1, row 0
         float *sd = s_d + (s % NS) * E * TTP, *sv = s_v + (s % NS) * TT * LD;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -232,9 +239,16 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
             else n = boot4;
             const float r4[4] = {r.x, r.y, r.z, r.w}, v4[4] = {v.x, v.y, v.z, v.w};
             const float n4[4] = {n.x, n.y, n.z, n.w};
+            float m4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MASKED) {
+              const float4 m = *(const float4 *)(raw_m + tl * E + 4 * q);
+              m4[0] = m.x; m4[1] = m.y; m4[2] = m.z; m4[3] = m.w;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              sd[(4 * q + c) * TTP + tl] = __fsub_rn(__fadd_rn(r4[c], __fmul_rn(gamma, n4[c])), v4[c]);
+              float gv = __fmul_rn(gamma, n4[c]);
+              if (MASKED) gv = __fmul_rn(gv, __fsub_rn(1.0f, m4[c]));
+              sd[(4 * q + c) * TTP + tl] = __fsub_rn(__fadd_rn(r4[c], gv), v4[c]);
               sv[tl * LD + 4 * q + c] = v4[c];
             }
           }
@@ -306,11 +320,52 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
       if (jc >= 0 && jc < ntiles && lane < E && !(dbg & 1)) {
         const int rows = t_hi(jc) - t_lo(jc);
         float *sd = s_d + (jc % NS) * E * TTP + lane * TTP;   // this env's row of the transposed tile
+        const float *sm = s_raw + (jc % NR) * SLOT + 2 * PLANE + lane;   // MASKED: done[tl] at sm[tl * E]
         int top = rows;
         for (; top & 7; --top) {   // ragged head of a partial tile, one step at a time
-          gae = __fadd_rn(sd[top - 1], __fmul_rn(gl, gae));
+          const float c = MASKED ? __fmul_rn(gl, __fsub_rn(1.0f, sm[(top - 1) * E])) : gl;
+          gae = __fadd_rn(sd[top - 1], __fmul_rn(c, gae));
           sd[top - 1] = gae;
         }
+        if (MASKED) {
+          // per-step coefficient gamma_lambda * (1 - done): formed off the dependent chain from
+          // the raw done plane, one group of 8 steps ahead
+          auto fetch_m = [&](f32x4 (&d)[2], float (&c)[8], int g) {
+            d[0] = *(const f32x4 *)(sd + g);
+            d[1] = *(const f32x4 *)(sd + g + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = sm[(g + i) * E];
+          };
+          auto run_m = [&](const f32x4 (&d)[2], const float (&m)[8], int g) {
+            float c[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = __fmul_rn(gl, __fsub_rn(1.0f, m[i]));
+            f32x4 lo4, hi4;
+            hi4[3] = gae = __fadd_rn(d[1][3], __fmul_rn(c[7], gae));
+            hi4[2] = gae = __fadd_rn(d[1][2], __fmul_rn(c[6], gae));
+            hi4[1] = gae = __fadd_rn(d[1][1], __fmul_rn(c[5], gae));
+            hi4[0] = gae = __fadd_rn(d[1][0], __fmul_rn(c[4], gae));
+            lo4[3] = gae = __fadd_rn(d[0][3], __fmul_rn(c[3], gae));
+            lo4[2] = gae = __fadd_rn(d[0][2], __fmul_rn(c[2], gae));
+            lo4[1] = gae = __fadd_rn(d[0][1], __fmul_rn(c[1], gae));
+            lo4[0] = gae = __fadd_rn(d[0][0], __fmul_rn(c[0], gae));
+            *(f32x4 *)(sd + g + 4) = hi4;
+            *(f32x4 *)(sd + g) = lo4;
+          };
+          f32x4 da[2], db[2];
+          float ma[8], mb[8];
+          int g = top - 8;                       // top is a multiple of 8 here
+          if (g >= 0) fetch_m(da, ma, g);
+          while (g >= 0) {
+            fetch_m(db, mb, g >= 8 ? g - 8 : 0);   // clamped: the last prefetch is discarded
+            run_m(da, ma, g);
+            g -= 8;
+            if (g < 0) break;
+            fetch_m(da, ma, g >= 8 ? g - 8 : 0);
+            run_m(db, mb, g);
+            g -= 8;
+          }
+        } else {
         // Full groups of 8 steps, branch-free, two register sets in ping-pong: the next group's
         // deltas are fetched from LDS (2 x ds_read_b128) while the current group runs down the
         // dependent chain (2 VALU ops per step) and goes back as 2 x ds_write_b128.
@@ -357,30 +412,38 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
             g -= 8;
           }
         }
+        }   // !MASKED
       }
       __syncthreads();
     }
   }
 }
 
-template <int E, int PF>
-int launch_pipe(const float *reward, const float *value, const float *bootstrap, int T, int N, float gamma,
-                float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
+template <int E, int PF, bool MASKED>
+int launch_pipe(const float *reward, const float *value, const float *done, const float *bootstrap, int T, int N,
+                float gamma, float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
   const int ngroups = (int)trl_cdiv(N, E);
-  hipLaunchKernelGGL((k_gae_pipe<E, PF>), dim3(ngroups), dim3(448), 0, st, reward, value, bootstrap, T, N, gamma,
-                     gl, out_nt, ngroups, returns, adv, dbg);
+  hipLaunchKernelGGL((k_gae_pipe<E, PF, MASKED>), dim3(ngroups), dim3(448), 0, st, reward, value, done, bootstrap, T,
+                     N, gamma, gl, out_nt, ngroups, returns, adv, dbg);
   TRL_CHECK_LAUNCH("trl_gae_reverse_scan");
   return TRL_OK;
 }
 
 // E and PF as run-time choices (0 = default heuristic); used by the dispatcher and the sweep tool
-int dispatch_pipe(int E, int PF, const float *reward, const float *value, const float *bootstrap, int T, int N,
-                  float gamma, float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
+int dispatch_pipe(int E, int PF, const float *reward, const float *value, const float *done, const float *bootstrap,
+                  int T, int N, float gamma, float gl, int out_nt, float *returns, float *adv, int dbg,
+                  hipStream_t st) {
   if (E == 0) E = N > 256 * 32 ? 64 : (N > 256 * 16 ? 32 : 16);
   if (PF == 0) PF = 2;   // deeper prefetch measured no faster, cold or cache-resident (tools/gae_sweep.py)
+  if (done) {            // masked extension: three planes per ring slot, the LDS holds PF = 2 at most
+#define TRL_PIPE_MCASE(e)  \
+  if (E == e) return launch_pipe<e, 2, true>(reward, value, done, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
+    TRL_PIPE_MCASE(16) TRL_PIPE_MCASE(32) TRL_PIPE_MCASE(64)
+#undef TRL_PIPE_MCASE
+  }
 #define TRL_PIPE_CASE(e, pf)  \
   if (E == e && PF == pf)     \
-    return launch_pipe<e, pf>(reward, value, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
+    return launch_pipe<e, pf, false>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
   TRL_PIPE_CASE(16, 2) TRL_PIPE_CASE(16, 3) TRL_PIPE_CASE(16, 4) 
   TRL_PIPE_CASE(32, 2) TRL_PIPE_CASE(32, 3) TRL_PIPE_CASE(32, 4)
   TRL_PIPE_CASE(64, 2) TRL_PIPE_CASE(64, 3) TRL_PIPE_CASE(64, 4)
@@ -426,13 +489,13 @@ extern "C" int trl_gae_reverse_scan(const float *reward, const float *value, con
   const bool aligned = N % 4 == 0 && ((uintptr_t)reward % 16 == 0) && ((uintptr_t)value % 16 == 0) &&
                        ((uintptr_t)bootstrap % 16 == 0) && ((uintptr_t)returns % 16 == 0) &&
                        (adv == nullptr || (uintptr_t)adv % 16 == 0);
-  if (aligned && !masked) {
+  if (aligned && (!masked || (uintptr_t)done % 16 == 0)) {
     // Envs per workgroup: 16 (a 64 B row segment) while that gives at most one workgroup per
     // CU (the pipelined kernel holds most of a CU's LDS), then wider segments.
     int E = 0, PF = 0, dbg = 0;
     if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d", &E, &PF, &dbg);   // tools/gae_sweep.py
-    return dispatch_pipe(E, PF, reward, value, bootstrap, (int)T, (int)N, gamma, gamma_lambda, out_layout,
-                         returns, adv, dbg, st);
+    return dispatch_pipe(E, PF, reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma,
+                         gamma_lambda, out_layout, returns, adv, dbg, st);
   }
   return launch<16>(masked, reward, value, done, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
                     out_layout, returns, adv, st);
