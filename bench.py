@@ -53,6 +53,9 @@ def parse():
   ap.add_argument('--epochs', type=int, default=4)
   ap.add_argument('--capacity', type=int, default=None)
   ap.add_argument('--kernel-iters', type=int, default=50)
+  ap.add_argument('--sampler', default='mt19937', choices=['mt19937', 'device'],
+                  help='off-policy loops: mt19937 = bit-exact torch.randperm prefix on the host (parity mode); '
+                       'device = Philox sampler on the GPU (throughput mode, not index-identical)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -391,8 +394,12 @@ def bench_offpolicy(args, rank, world, dev, atari):
     row_bytes, name = 36, 'ddpg_pendulum'
     wl = 'ddpg: %d-row Pendulum-shaped f32 replay per GPU, actor/critic MLP 256x256' % cap
 
-  def step():
-    ctl.learn(*ds.sample(B))     # MT19937 randperm-prefix (host) + HIP gather + fused loss/update
+  if args.sampler == 'device':
+    def step():
+      ctl.learn(*ds.sample_device(B))   # Philox sampler kernel + HIP gather + fused loss/update, no host RNG work
+  else:
+    def step():
+      ctl.learn(*ds.sample(B))     # MT19937 randperm-prefix (host) + HIP gather + fused loss/update
 
   dt = timed_steps(step, steps, warmup, world)
   value = B * steps * world / dt
@@ -410,7 +417,8 @@ def bench_offpolicy(args, rank, world, dev, atari):
       'metric': 'learner transitions/sec (sample+loss+update)', 'value': round(value, 1), 'unit': 'transitions/s',
       'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-      'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix (bit-exact)',
+      'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix on the host (bit-exact)' if args.sampler == 'mt19937' else
+                 'philox on the device (throughput mode, not index-identical to torch.randperm)',
                  'parallelism': 'dp%d' % world, 'name': name,
                  'learn_step': 'hip-graph replay' if args.use_graph else 'eager'},
       'roofline': roof,

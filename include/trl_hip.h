@@ -101,6 +101,17 @@ int trl_mt19937_seed(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, uint6
 int trl_randperm_prefix(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, int64_t n, int64_t B,
                         int64_t *out_h);
 
+/* Throughput-mode sampler, on the device: B distinct indices uniform over [0, n) written to
+ * idx_d (device int64 [B]), ready for trl_gather_rows -- the same distribution as
+ * `torch.randperm(n)[:B]` (examples/dqn.py:40) but NOT the same indices (bit-exact indices are
+ * trl_randperm_prefix above, O(n) host work per call; this is O(B) device work and needs no
+ * host round trip, so a whole sample -> gather -> learn step can be queued or graph-replayed).
+ * Counter-based (Philox-4x32-10 keyed by `seed`); *call_counter_d (device u64) numbers the calls and
+ * is incremented by the launch; the result depends on (seed, call number, n, B) only.
+ * 0 <= B <= min(n, 4096). */
+int trl_sample_indices(int64_t n, int64_t B, uint64_t seed, uint64_t *call_counter_d, int64_t *idx_d,
+                       void *stream);
+
 /* ------------------------------------------------------------------ returns / GAE (a-3)
  * Replaces the Python reverse loop of A2CController.compute_return
  * (a2c_controller.py:38-43) and PPOController.compute_return (ppo_controller.py:41-46)

@@ -198,3 +198,46 @@ def test_large_ring_properties():
   assert torch.equal(obs[:, 0], r) and torch.equal(obs[:, 2], r + 0.5)
   assert torch.equal(act[:, 0], r * 2) and torch.equal(rew[:, 0], -r)
   assert torch.equal(nobs[:, 1], r + 1.25) and torch.equal(done[:, 0], r % 2)
+
+
+def test_device_sampler_distinct_uniform_reproducible():
+  """Throughput-mode sampler (trl_sample_indices): distinct indices in range, a function of
+  (seed, call number) only, uniform over the rows; the gathered batch is ds[indices]."""
+  dev = torch.device(DEV)
+  n = 5000
+  ds = TensorTupleDataset(size=n, device=dev)
+  cols = [torch.arange(n, dtype=torch.float32, device=dev).view(n, 1), torch.randn(n, 3, device=dev)]
+  ds.extend(*cols)
+  runs = []
+  for _ in range(2):
+    ds._dev_rng = None
+    seq = []
+    for _call in range(3):
+      batch = ds.sample_device(256, seed=1234)
+      idx = ds.last_indices.cpu()
+      assert idx.numel() == 256 and idx.unique().numel() == 256 and int(idx.min()) >= 0 and int(idx.max()) < n
+      assert torch.equal(batch[0].view(-1).cpu(), idx.float())           # row i of column 0 holds i
+      assert torch.equal(batch[1].cpu(), cols[1].cpu()[idx])
+      seq.append(idx)
+    runs.append(seq)
+  for a, b in zip(*runs):
+    assert torch.equal(a, b)                                             # same seed, same call number
+  assert not torch.equal(runs[0][0], runs[0][1])                          # successive calls differ
+  # every row when B == n (maximal collision pressure), and the largest batch
+  small = TensorTupleDataset(size=300, device=dev)
+  small.extend(torch.arange(300, dtype=torch.float32, device=dev).view(300, 1))
+  small.sample_device(300, seed=7)
+  assert torch.equal(small.last_indices.sort().values.cpu(), torch.arange(300))
+  ds.sample_device(4096, seed=5)
+  assert ds.last_indices.unique().numel() == 4096
+  with pytest.raises(Exception):
+    ds.sample_device(4097)
+  # uniformity: 400 calls x 250 draws over 50 buckets of 100 rows, chi-square with 49 dof
+  counts = torch.zeros(50)
+  ds._dev_rng = None
+  for _ in range(400):
+    ds.sample_device(250, seed=99)
+    counts += torch.bincount((ds.last_indices // 100).cpu(), minlength=50).float()
+  expect = 400 * 250 / 50
+  chi2 = float(((counts - expect) ** 2 / expect).sum())
+  assert chi2 < 95.0, chi2        # p ~ 1e-4 for 49 dof

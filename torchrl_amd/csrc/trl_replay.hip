@@ -423,3 +423,109 @@ extern "C" int trl_ring_push(void *ring, int64_t capacity, int64_t stride, const
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
 }
+
+// ------------------------------------------------------------------------------ device sampler
+// B distinct indices uniform over [0, n), drawn on the device: the throughput-mode counterpart
+// of `torch.randperm(n)[:B]` (examples/dqn.py:40).  NOT index-identical to torch (that is
+// trl_randperm_prefix, on the host, O(n) per call): a counter-based generator (Philox-4x32-10
+// keyed by the seed, counter = (call number, sample position, attempt)) gives every position its
+// own stream; duplicates are resolved in rounds through an LDS hash set in which the earlier
+// round, then the lower position, keeps an index and the other redraws -- so the result is a
+// function of (seed, call number, n, B) alone, whatever the scheduling.  One workgroup.
+namespace {
+
+constexpr int SAMP_MAX_B = 4096;
+constexpr int SAMP_SLOTS = 2 * SAMP_MAX_B;     // open addressing, load factor <= 0.5
+constexpr uint32_t SAMP_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1;
+  c[3] = (uint32_t)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+
+__device__ __forceinline__ uint64_t philox64(uint64_t seed, uint64_t call, uint32_t pos, uint32_t attempt) {
+  uint32_t c[4] = {(uint32_t)call, (uint32_t)(call >> 32), pos, attempt};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return ((uint64_t)c[0] << 32) | c[1];
+}
+
+__global__ __launch_bounds__(1024) void k_sample_distinct(int64_t n, int B, uint64_t seed,
+                                                          unsigned long long *__restrict__ call_counter,
+                                                          int64_t *__restrict__ out) {
+  __shared__ uint32_t s_key[SAMP_SLOTS];     // the index held by a slot
+  __shared__ uint32_t s_own[SAMP_SLOTS];     // (round << 12 | position) of its best claimant
+  __shared__ int s_pending;
+  const uint64_t call = *call_counter;
+  for (int i = threadIdx.x; i < SAMP_SLOTS; i += 1024) { s_key[i] = SAMP_EMPTY; s_own[i] = SAMP_EMPTY; }
+  __syncthreads();
+  // thread t owns positions t, t + 1024, ... (at most 4)
+  uint32_t cand[4], slot[4], attempt[4];
+  bool pend[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { pend[j] = (int)threadIdx.x + 1024 * j < B; attempt[j] = 0; cand[j] = slot[j] = 0; }
+  for (uint32_t round = 0; round < (1u << 19); ++round) {
+    if (threadIdx.x == 0) s_pending = 0;
+    __syncthreads();
+    // claim: find (or make) the slot of the candidate, leave the best claimant in s_own
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!pend[j]) continue;
+      const uint32_t pos = threadIdx.x + 1024 * j;
+      const uint64_t u = philox64(seed, call, pos, attempt[j]);
+      cand[j] = (uint32_t)__umul64hi(u, (uint64_t)n);           // uniform over [0, n), bias < n / 2^64
+      uint32_t s = (cand[j] * 0x9E3779B1u) >> 19;                  // 13 bits -> SAMP_SLOTS
+      for (;;) {
+        const uint32_t old = atomicCAS(&s_key[s], SAMP_EMPTY, cand[j]);
+        if (old == SAMP_EMPTY || old == cand[j]) break;
+        s = (s + 1) & (SAMP_SLOTS - 1);
+      }
+      slot[j] = s;
+      atomicMin(&s_own[s], (round << 12) | pos);
+    }
+    __syncthreads();
+    // settle: the owner keeps the index, everyone else redraws next round
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!pend[j]) continue;
+      const uint32_t pos = threadIdx.x + 1024 * j;
+      if (s_own[slot[j]] == ((round << 12) | pos)) {
+        out[pos] = (int64_t)cand[j];
+        pend[j] = false;
+      } else {
+        ++attempt[j];
+        atomicAdd(&s_pending, 1);
+      }
+    }
+    __syncthreads();
+    if (s_pending == 0) break;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *call_counter = call + 1;
+}
+
+}  // namespace
+
+extern "C" int trl_sample_indices(int64_t n, int64_t B, uint64_t seed, uint64_t *call_counter_d, int64_t *idx_d,
+                                  void *stream) {
+  const char *fn = "trl_sample_indices";
+  TRL_REQUIRE(call_counter_d && idx_d, "%s: null pointer", fn);
+  TRL_REQUIRE((uintptr_t)call_counter_d % 8 == 0, "%s: the call counter must be 8-byte aligned", fn);
+  TRL_REQUIRE(n >= 1 && n < (1ll << 32) - 1, "%s: n=%lld out of range", fn, (long long)n);
+  TRL_REQUIRE(B >= 0 && B <= SAMP_MAX_B && B <= n, "%s: need 0 <= B <= min(n, %d), got B=%lld n=%lld", fn, SAMP_MAX_B,
+              (long long)B, (long long)n);
+  if (B == 0) return TRL_OK;
+  hipLaunchKernelGGL(k_sample_distinct, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, (int)B, seed,
+                     (unsigned long long *)call_counter_d, idx_d);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}

@@ -370,6 +370,25 @@ class TensorTupleDataset(Dataset):
     idx = randperm_prefix(self._count, batch_size, generator)
     return self._gather_index(self._index_to_device(idx))
 
+  def sample_device(self, batch_size, seed=None):
+    """Throughput mode: `batch_size` distinct rows drawn uniformly ON THE DEVICE (trl_sample_indices,
+    Philox) and gathered, with no host work per call beyond two launches -- the step can be queued
+    or graph-replayed.  Same distribution as `sample()`, NOT the same indices as
+    `torch.randperm` (for parity use `sample()`).  `seed` (first call only) defaults to
+    torch.initial_seed().  Returns the batch; the indices stay in `self.last_indices`."""
+    if self._layout is None or self._count == 0:
+      raise TypeError("'NoneType' object is not iterable")
+    B = int(batch_size)
+    if getattr(self, '_dev_rng', None) is None:
+      self._dev_seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)
+      self._dev_rng = torch.zeros(1, dtype=torch.int64, device=self._device)     # the call counter
+    idx = torch.empty(B, dtype=torch.int64, device=self._device)
+    with torch.cuda.device(self._device):
+      _lib.check(_lib.lib().trl_sample_indices(self._count, B, C.c_uint64(self._dev_seed), self._dev_rng.data_ptr(),
+                                               idx.data_ptr(), _lib.stream_ptr(self._device)))
+    self.last_indices = idx
+    return self._gather_index(idx)
+
   def iter_batches(self, batch_size):
     """Sequential minibatches, last partial batch kept: the order of
     `DataLoader(ds, batch_size=...)` at examples/ppo.py:68 without per-row collation."""
