@@ -291,6 +291,16 @@ int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         float *losses_out, float *const *critic_grads, float *const *actor_grads,
                         float *dlog_std, const trl_adam_args *adam, void *ws, void *stream);
 
+/* The same for A2CController.learn (a2c_controller.py:47-69) with A2CNet's critic and softmax
+ * actor (models.py:84-109; `actor` describes the Linear layers, the softmax is applied inside):
+ *   action [B] (the index, as f32), returns [B], adv [B] = returns - V(obs) DETACHED -- computed
+ *   by the caller with trl_ppo_forward_fused(critic), which evaluates V bit-identically to this
+ *   kernel's own critic pass.  losses_out as above (actor, critic, entropy, total). */
+int trl_a2c_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *obs,
+                        const float *action, const float *returns, const float *adv, int64_t B, int32_t A,
+                        double alpha, double beta, float *losses_out, float *const *critic_grads,
+                        float *const *actor_grads, const trl_adam_args *adam, void *ws, void *stream);
+
 /* The forward alone of the same networks over B rows, only the outputs written: the value /
  * mean / log-prob pass of PPOController.compute_return (ppo_controller.py:34, 48) and act().
  *   value [B] (needs critic), mean [B, A], logp [B, A] = Normal(mean, exp(log_std)).log_prob(action)

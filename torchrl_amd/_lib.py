@@ -82,6 +82,8 @@ PROTOTYPES = {
     'trl_mlp_bwd_group': (C.c_int, [C.POINTER(MlpDesc), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i64,
                                     C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     'trl_ppo_learn_workspace_bytes': (_i64, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _i64]),
+    'trl_a2c_learn_fused': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64,
+                                      _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(AdamArgs), _vp, _vp]),
     'trl_ppo_forward_fused': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp,
                                         _vp]),
     'trl_ppo_learn_fused': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i64,

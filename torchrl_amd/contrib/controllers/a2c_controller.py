@@ -1,4 +1,6 @@
 """A2C controller on the GAE scan and fused loss kernels (reference: a2c_controller.py)."""
+import os
+
 import torch
 
 from ...controllers import Controller
@@ -21,6 +23,11 @@ class A2CController(Controller):
     self.ac_net_optim = FlatAdam(self._flat, lr=lr, grad_scale=self._sync.scale, device_state=graph)
     for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
       stack.direct_grads = True
+    self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); TRL_FUSED_LEARN=0 disables
+    if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+      lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
+      if F.FusedPpoLearn.supports(lins[0], lins[1], None):
+        self._fused = F.FusedPpoLearn(lins[0], lins[1], None)
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma
@@ -52,14 +59,27 @@ class A2CController(Controller):
     need_hip(self.device, 'A2CController.compute_return')
     T, N = reward.shape
     with torch.no_grad():
-      values = self.ac_net.critic(obs.reshape(T * N, -1)).view(T, N)
-      bootstrap = self.ac_net.critic(last_next_obs).view(N)
+      flat_obs = obs.reshape(T * N, -1)
+      if self._fused is not None and self._fused.usable(flat_obs) and self._fused.usable(last_next_obs):
+        values = self._fused.forward(flat_obs, want_mean=False)[0].view(T, N)      # forward-only kernel
+        bootstrap = self._fused.forward(last_next_obs, want_mean=False)[0]
+      else:
+        values = self.ac_net.critic(flat_obs).view(T, N)
+        bootstrap = self.ac_net.critic(last_next_obs).view(N)
       bootstrap = torch.where(last_done.reshape(N) != 0, torch.zeros_like(bootstrap), bootstrap)
       returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
                            env_major_out=env_major_out)
     return returns, adv, values
 
   def _learn_body(self, obs, action, returns):
+    if self._fused is not None and self._fused.usable(obs):
+      solo = not self._sync.enabled
+      in_kernel = solo and not self.ac_net_optim.device_state    # eager single rank: update inside the reduce launch
+      losses = self._fused.a2c(obs, action, returns, self.alpha, self.beta,
+                               adam=self.ac_net_optim if in_kernel else None)
+      if solo and not in_kernel:
+        self.ac_net_optim.step()
+      return losses[:3]
     value, probs = self.ac_net.heads(obs)
     loss, parts = F.a2c_loss(probs, value, action, returns, self.alpha, self.beta)
     self.ac_net_optim.zero_grad()

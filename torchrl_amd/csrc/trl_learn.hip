@@ -67,10 +67,14 @@ struct LearnArgs {
   const float *obs, *action, *returns, *old_logp, *adv, *log_std;
   int64_t B;
   int32_t A;
+  int32_t kind;         // KIND_PPO: Normal policy, clipped surrogate; KIND_A2C: softmax policy, adv * log-prob
   float lo, hi, alpha, beta;
   float *ws;            // [2][gridDim.x][pstride]
   int32_t pstride;
 };
+constexpr int KIND_PPO = 0, KIND_A2C = 1;
+constexpr float F32_EPS = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps
+constexpr float F32_LOWEST = -3.4028234663852886e+38f;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   for (int n = 0; n < NO; ++n) {
     s_dls[n] = 0.f;
     den[n] = var[n] = 1.f; logsig[n] = 0.f;
-    if (net == 1 && n < A) {
+    if (net == 1 && P.kind == KIND_PPO && n < A) {
       const float sigma = expf(P.log_std[n]);   // self.log_std.exp()
       var[n] = sigma * sigma;                   // scale ** 2
       logsig[n] = logf(sigma);                  // scale.log()
@@ -379,11 +383,12 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // critic and the padded dimensions re-read slot 0's array: always a valid address)
   const float *in0 = net == 0 ? P.returns : P.adv;
   const float *in_act[NO], *in_olp[NO];
-  const int astr = net == 0 ? 1 : A;
+  const bool ppo_actor = net == 1 && P.kind == KIND_PPO;
+  const int astr = ppo_actor ? A : 1;
 #pragma unroll
-  for (int n = 0; n < NO; ++n) {
-    in_act[n] = net == 0 ? in0 : P.action + (n < A ? n : 0);
-    in_olp[n] = net == 0 ? in0 : P.old_logp + (n < A ? n : 0);
+  for (int n = 0; n < NO; ++n) {      // A2C: the action index of the row, in every slot
+    in_act[n] = net == 0 ? in0 : (ppo_actor ? P.action + (n < A ? n : 0) : P.action);
+    in_olp[n] = ppo_actor ? P.old_logp + (n < A ? n : 0) : in0;
   }
   float xr[XPF], p_in0 = 0.f, p_act[NO], p_olp[NO];
 #pragma unroll
@@ -460,6 +465,58 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       const float dv = out[0] - ret;            // mse_loss(values, returns)
       if (count) s_main += dv * dv;
       if (valid) gout[0] = P.alpha * ((2.0f * invB) * dv);
+    } else if (P.kind == KIND_A2C) {
+      // out = the actor's logits; nn.Softmax(dim=1) (models.py:99-103), then Categorical(probs) and
+      // the loss of a2c_controller.py:48-59 in the arithmetic of k_a2c_loss; `ad` is the detached
+      // advantage returns - V(obs) (the caller's forward-only pass)
+      float zmax = out[0];
+#pragma unroll
+      for (int n = 1; n < NO; ++n)
+        if (n < A) zmax = fmaxf(zmax, out[n]);
+      float pr[NO], esum = 0.f;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        pr[n] = n < A ? expf(out[n] - zmax) : 0.f;
+        esum += pr[n];
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        pr[n] = pr[n] / esum;
+        s += pr[n];                             // Categorical: probs / probs.sum(-1, keepdim=True)
+      }
+      int ai = (int)act[0];                     // action.long()
+      ai = ai < 0 ? 0 : (ai >= A ? A - 1 : ai);
+      float ent = 0.f, gdot = 0.f, logp = 0.f, gg[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        gg[n] = 0.f;
+        if (n < A) {
+          const float pn = pr[n] / s;
+          const float cl = fminf(fmaxf(pn, F32_EPS), 1.0f - F32_EPS);   // clamp_probs
+          const float logit = logf(cl);
+          ent += fmaxf(logit, F32_LOWEST) * pn;
+          if (n == ai) logp = logit;
+          const float dlogit = (pn >= F32_EPS && pn <= 1.0f - F32_EPS) ? 1.0f / cl : 0.f;
+          float g1 = (P.beta * invB) * (logit + pn * dlogit);          // from -beta * entropy
+          if (n == ai) g1 += (-(ad * invB)) * dlogit;                   // from the actor term
+          gg[n] = g1;
+          gdot += g1 * pn;
+        }
+      }
+      float dp[NO], dsum = 0.f;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        dp[n] = n < A ? (gg[n] - gdot) / s : 0.f;                       // back through the normalisation
+        dsum += dp[n] * pr[n];
+      }
+#pragma unroll
+      for (int n = 0; n < NO; ++n)
+        if (valid && n < A) gout[n] = (dp[n] - dsum) * pr[n];            // softmax backward
+      if (count) {
+        s_main += ad * logp;
+        s_ent += -ent;
+      }
     } else {
 #pragma unroll
       for (int n = 0; n < NO; ++n) {
@@ -858,6 +915,7 @@ struct ReduceArgs {
   float *dlog_std;    // [A]
   int64_t B;
   int32_t A;
+  int32_t kind;
   float alpha, beta, dls_ent;
   // optional update stage: param / moments of gradient element g are at (g - grad) in these
   int32_t do_adam;
@@ -915,7 +973,8 @@ __global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_bl
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float invBA = 1.0f / (float)(R.B * R.A);
+    // PPO: the surrogate and the entropy are means over [B, A]; A2C: means over the batch
+    const float invBA = 1.0f / (float)(R.kind == KIND_A2C ? R.B : R.B * R.A);
     const float actor = -(partS[0][1] * invBA);
     const float critic = partS[0][0] * (1.0f / (float)R.B);
     const float ent = partS[0][2] * invBA;
@@ -924,7 +983,7 @@ __global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_bl
     R.losses[2] = ent;
     R.losses[3] = (actor + R.alpha * critic) - R.beta * ent;
   }
-  if ((int)threadIdx.x < R.A && threadIdx.x < 5) {
+  if (R.dlog_std && (int)threadIdx.x < R.A && threadIdx.x < 5) {
     float *gp = R.dlog_std + threadIdx.x;
     *gp = partS[0][3 + threadIdx.x] + R.dls_ent;
     if (R.do_adam) {
@@ -995,16 +1054,15 @@ extern "C" int64_t trl_ppo_learn_workspace_bytes(const trl_mlp_desc *critic, con
   return 2ll * MAX_WG * pstride_of(np[0], np[1]) * 4;
 }
 
-extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
-                                   const float *obs, const float *action, const float *returns,
-                                   const float *old_logp, const float *adv, int64_t B, int32_t A, double clip,
-                                   double alpha, double beta, float *losses_out, float *const *critic_grads,
-                                   float *const *actor_grads, float *dlog_std, const trl_adam_args *adam, void *ws,
-                                   void *stream) {
-  const char *fn = "trl_ppo_learn_fused";
-  TRL_REQUIRE(log_std && obs && action && returns && old_logp && adv && losses_out && critic_grads && actor_grads &&
-                  dlog_std && ws,
-              "%s: null pointer", fn);
+namespace {
+int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                const float *obs, const float *action, const float *returns, const float *old_logp, const float *adv,
+                int64_t B, int32_t A, double clip, double alpha, double beta, float *losses_out,
+                float *const *critic_grads, float *const *actor_grads, float *dlog_std, const trl_adam_args *adam,
+                void *ws, void *stream) {
+  TRL_REQUIRE(obs && action && returns && adv && losses_out && critic_grads && actor_grads && ws, "%s: null pointer",
+              fn);
+  TRL_REQUIRE(kind == KIND_A2C || (log_std && old_logp && dlog_std), "%s: null pointer", fn);
   TRL_REQUIRE(B > 0 && B < (1ll << 31), "%s: B=%lld out of range", fn, (long long)B);
   TRL_REQUIRE(A >= 1 && A <= 4, "%s: action size %d not in [1, 4]", fn, A);
   TRL_REQUIRE(critic && actor, "%s: null network description", fn);
@@ -1019,7 +1077,7 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
   TRL_REQUIRE(critic->depth == actor->depth && critic->dims[0] == actor->dims[0],
               "%s: critic and actor must have the same depth and observation size", fn);
   P.obs = obs; P.action = action; P.returns = returns; P.old_logp = old_logp; P.adv = adv; P.log_std = log_std;
-  P.B = B; P.A = A;
+  P.B = B; P.A = A; P.kind = kind;
   P.lo = (float)(1.0 - clip); P.hi = (float)(1.0 + clip); P.alpha = (float)alpha; P.beta = (float)beta;
   P.ws = (float *)ws;
   P.pstride = pstride_of(P.net[0].nparams, P.net[1].nparams);
@@ -1031,13 +1089,13 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
   if (rc) return rc;
   rc = fill_dst(fn, P.net[1], actor_grads, &R.gd[1]);
   if (rc) return rc;
-  R.losses = losses_out; R.dlog_std = dlog_std; R.B = B; R.A = A;
+  R.losses = losses_out; R.dlog_std = dlog_std; R.B = B; R.A = A; R.kind = kind;
   R.alpha = P.alpha; R.beta = P.beta; R.dls_ent = (float)(-beta / (double)A);
   if (adam) {
     TRL_REQUIRE(adam->param && adam->grad && adam->exp_avg && adam->exp_avg_sq && adam->n > 0 && adam->step >= 1,
                 "%s: incomplete adam arguments", fn);
     const float *lo = adam->grad, *hi = adam->grad + adam->n;
-    bool inside = dlog_std >= lo && dlog_std + A <= hi;
+    bool inside = dlog_std == nullptr || (dlog_std >= lo && dlog_std + A <= hi);
     for (int g = 0; g < 2; ++g)
       for (int j = 0; j < R.gd[g].nseg; ++j)
         inside = inside && R.gd[g].dst[j] >= lo && R.gd[g].dst[j] + (R.gd[g].start[j + 1] - R.gd[g].start[j]) <= hi;
@@ -1068,6 +1126,25 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
   hipLaunchKernelGGL(k_learn_reduce, dim3((unsigned)pblocks + 1, 2), dim3(256), 0, st, R, pblocks);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
+}
+}  // namespace
+
+extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                   const float *obs, const float *action, const float *returns,
+                                   const float *old_logp, const float *adv, int64_t B, int32_t A, double clip,
+                                   double alpha, double beta, float *losses_out, float *const *critic_grads,
+                                   float *const *actor_grads, float *dlog_std, const trl_adam_args *adam, void *ws,
+                                   void *stream) {
+  return learn_fused("trl_ppo_learn_fused", KIND_PPO, critic, actor, log_std, obs, action, returns, old_logp, adv, B, A,
+                     clip, alpha, beta, losses_out, critic_grads, actor_grads, dlog_std, adam, ws, stream);
+}
+
+extern "C" int trl_a2c_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *obs,
+                                   const float *action, const float *returns, const float *adv, int64_t B, int32_t A,
+                                   double alpha, double beta, float *losses_out, float *const *critic_grads,
+                                   float *const *actor_grads, const trl_adam_args *adam, void *ws, void *stream) {
+  return learn_fused("trl_a2c_learn_fused", KIND_A2C, critic, actor, nullptr, obs, action, returns, nullptr, adv, B, A,
+                     0.0, alpha, beta, losses_out, critic_grads, actor_grads, nullptr, adam, ws, stream);
 }
 
 extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,

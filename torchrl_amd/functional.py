@@ -474,10 +474,13 @@ class FusedPpoLearn:
 
   @staticmethod
   def supports(critic_lin, actor_lin, log_std):
+    """log_std: ActorCriticNet's parameter (PPO), or None for A2CNet's softmax actor (A2C)."""
     if len(critic_lin) != len(actor_lin) or len(critic_lin) not in (2, 3):
       return False
     A = actor_lin[-1].out_features
-    if critic_lin[-1].out_features != 1 or log_std.numel() != A or A > (2 if len(critic_lin) == 3 else 4):
+    if critic_lin[-1].out_features != 1 or A > (2 if len(critic_lin) == 3 else 4):
+      return False
+    if log_std is not None and log_std.numel() != A:
       return False
     if critic_lin[0].in_features != actor_lin[0].in_features:
       return False
@@ -495,14 +498,16 @@ class FusedPpoLearn:
     self.critic_lin, self.actor_lin, self.log_std = list(critic_lin), list(actor_lin), log_std
     self.A = actor_lin[-1].out_features
     self.K0 = critic_lin[0].in_features
-    self.device = log_std.device
+    self.device = critic_lin[0].weight.device
     self._key = None
     self._bind()
 
   def _ptr_key(self):
-    return (self.critic_lin[0].weight.data_ptr(), self.actor_lin[-1].bias.data_ptr(), self.log_std.data_ptr(),
+    ls = self.log_std
+    return (self.critic_lin[0].weight.data_ptr(), self.actor_lin[-1].bias.data_ptr(),
+            ls.data_ptr() if ls is not None else 0,
             self.critic_lin[0].weight.grad.data_ptr() if self.critic_lin[0].weight.grad is not None else 0,
-            self.log_std.grad.data_ptr() if self.log_std.grad is not None else 0)
+            ls.grad.data_ptr() if ls is not None and ls.grad is not None else 0)
 
   def _bind(self):
     C = self._C
@@ -511,7 +516,7 @@ class FusedPpoLearn:
     for g, lin in enumerate((self.critic_lin, self.actor_lin)):
       ws_ = [m.weight for m in lin]
       bs_ = [m.bias for m in lin]
-      for t in ws_ + bs_ + [self.log_std]:
+      for t in ws_ + bs_ + ([self.log_std] if self.log_std is not None else []):
         if t.grad is None or not t.grad.is_contiguous() or not t.is_contiguous():
           raise ValueError('FusedPpoLearn needs contiguous parameters with an existing contiguous .grad')
       _fill_desc(self.descs[g], ws_, bs_)
@@ -542,7 +547,7 @@ class FusedPpoLearn:
     logp = torch.empty((B, self.A), dtype=torch.float32, device=dev) if action is not None else None
     with torch.cuda.device(dev):
       _lib.check(_lib.lib().trl_ppo_forward_fused(
-          C.byref(self.descs[0]), C.byref(self.descs[1]), self.log_std.data_ptr(), obs.data_ptr(), _lib.ptr(action),
+          C.byref(self.descs[0]), C.byref(self.descs[1]), _lib.ptr(self.log_std), obs.data_ptr(), _lib.ptr(action),
           B, self.A, _lib.ptr(value), _lib.ptr(mean), _lib.ptr(logp), _lib.stream_ptr(dev)))
     return value, mean, logp
 
@@ -573,4 +578,29 @@ class FusedPpoLearn:
           action.data_ptr(), returns.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), B, self.A, float(clip),
           float(alpha), float(beta), losses.data_ptr(), self.gradp[0], self.gradp[1],
           self.log_std.grad.data_ptr(), aref, ws.data_ptr(), _lib.stream_ptr(dev)))
+    return losses
+
+  def a2c(self, obs, action, returns, alpha, beta, adam=None):
+    """A2CController.learn's device work for A2CNet stacks (trl_a2c_learn_fused): a forward-only
+    pass gives the detached advantage returns - V, then one launch for forward + loss + backward
+    and one for the reduction (+ Adam).  Returns the [4] loss tensor."""
+    C = self._C
+    B = obs.shape[0]
+    obs = _f32c(obs, 'obs')
+    action = _f32c(action, 'action')
+    returns = _f32c(returns, 'returns')
+    if action.numel() != B or returns.numel() != B:
+      raise ValueError('a2c_learn_fused: inconsistent shapes')
+    value, _, _ = self.forward(obs, want_mean=False)
+    adv = returns.view(-1) - value
+    dev = obs.device
+    lib = _lib.lib()
+    ws = _linear_ws(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    aref = C.byref(adam.fused_args()) if adam is not None else None
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_a2c_learn_fused(
+          C.byref(self.descs[0]), C.byref(self.descs[1]), obs.data_ptr(), action.data_ptr(), returns.data_ptr(),
+          adv.data_ptr(), B, self.A, float(alpha), float(beta), losses.data_ptr(), self.gradp[0], self.gradp[1],
+          aref, ws.data_ptr(), _lib.stream_ptr(dev)))
     return losses
