@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
   __shared__ float sW[NB * 32 * LD];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t row0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * NB * 32;   // small batches split the fan-out over blockIdx.y to fill the chip
   f32x16 acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
   TileRegs<KC, VEC> rx;
   TileRegs<KC, VEC, NB * 32> rw;     // the weight chunk [fan-out, KC] takes the same route
   rx.load(x, B, K, row0, 0);
-  rw.load(w, N, K, 0, 0);
+  rw.load(w, N, K, n0, 0);
   for (int k0 = 0; k0 < K; k0 += KC) {
     __syncthreads();                     // readers of the previous chunk are done
     rx.template store<LD>(sX);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
     __syncthreads();
     if (k0 + KC < K) {
       rx.load(x, B, K, row0, k0 + KC);
-      rw.load(w, N, K, 0, k0 + KC);
+      rw.load(w, N, K, n0, k0 + KC);
     }
     // fixed trip count (the tiles are zero-padded) so that the operand reads of the next
     // k-steps are issued ahead of the MFMAs that consume them
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
   }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int col = nb * 32 + (lane & 31);
+    const int col = n0 + nb * 32 + (lane & 31);
     const float bias = col < N ? b[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -619,9 +620,13 @@ extern "C" int trl_linear_fwd(const float *x, const float *w, const float *b, in
   if (rc) return rc;
   TRL_REQUIRE(x && w && b && y, "%s: null pointer", fn);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)trl_cdiv(B, BM)), block(256);
-  const int NBv = N <= 32 ? 1 : (N <= 64 ? 2 : (N <= 128 ? 4 : 8));
+  // a workgroup owns 128 rows x NBv * 32 columns; with few row tiles (small batches: the off-policy
+  // learners' 32-256 rows) the fan-out is split one 32-column block per workgroup so that the
+  // launch covers more than a handful of CUs
+  int NBv = N <= 32 ? 1 : (N <= 64 ? 2 : (N <= 128 ? 4 : 8));
+  if (trl_cdiv(B, BM) < 32) NBv = 1;
   const int KBv = (K > 32 && NBv <= 4) ? 2 : 1;
+  const dim3 grid((unsigned)trl_cdiv(B, BM), (unsigned)trl_cdiv(N, NBv * 32)), block(256);
   const bool vec = K % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0;
 #define TRL_FWD_CASE(nb, kb)                                                                                     \
   if (NBv == nb && KBv == kb) {                                                                                  \
