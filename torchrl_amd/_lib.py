@@ -101,6 +101,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
       raise TrlError('%s not found: build it with `python -m torchrl_amd._build` '
                      '(there is no CPU fallback)' % LIB_PATH)
+    # torch first: its bundled HIP runtime must be the one in the process.  Loaded the other way
+    # round, libtrl_hip.so pulls in the system libamdhip64 and torch then finds no device.
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
       fn = getattr(handle, name)   # AttributeError if the symbol is missing
