@@ -120,7 +120,9 @@ def kernel_time_us(launch, iters):
     launch()
   torch.cuda.synchronize()
   g = torch.cuda.CUDAGraph()
-  with torch.cuda.graph(g):
+  # thread_local: other threads of the process (the collective watchdog of a multi-rank run) may
+  # keep calling HIP while this one captures
+  with torch.cuda.graph(g, capture_error_mode='thread_local'):
     for _ in range(iters):
       launch()
   g.replay()
