@@ -54,7 +54,7 @@ def main():
   cp = [(lambda s=s: s[3][0].copy_(s[0])) for s in sets]
   us = graph_time_us(cp)
   print('torch copy r -> ret (8 B/elem): %.1f us  %.0f GB/s' % (us, 8 * T * N / us / 1e3))
-  configs = [(16, PF, d) for PF in (2, 3) for d in (0, 16, 32, 48, 1, 17, 33, 49)]
+  configs = [(16, PF, d) for PF in (2, 3) for d in (0, 1, 2, 3, 8, 9, 10, 11)] + [(32, 2, 0), (32, 3, 0), (32, 3, 1)]
   for E, PF, dbg in configs:
     os.environ['TRL_GAE_TUNE'] = '%d,%d,%d' % (E, PF, dbg)
     try:
