@@ -56,6 +56,8 @@ def parse():
   ap.add_argument('--sampler', default='mt19937', choices=['mt19937', 'device'],
                   help='off-policy loops: mt19937 = bit-exact torch.randperm prefix on the host (parity mode); '
                        'device = Philox sampler on the GPU (throughput mode, not index-identical)')
+  ap.add_argument('--no-gemm-tuning', action='store_true',
+                  help='off-policy loops: keep the BLAS default kernel picks (default: PyTorch TunableOp chooses per shape)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -363,6 +365,9 @@ def gather_roofline(dev, iters, rows, B, atari):
 def bench_offpolicy(args, rank, world, dev, atari):
   steps = args.steps if args.steps is not None else 200
   warmup = args.warmup if args.warmup is not None else 20
+  if not args.no_gemm_tuning:
+    from torchrl_amd.tuning import enable_gemm_tuning
+    enable_gemm_tuning()     # 32-256-row GEMMs: the BLAS default pick is 4-5x off its best kernel
   g = torch.Generator(device=dev).manual_seed(100 + rank)
   torch.manual_seed(0)
   if atari:
@@ -422,6 +427,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
       'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix on the host (bit-exact)' if args.sampler == 'mt19937' else
                  'philox on the device (throughput mode, not index-identical to torch.randperm)',
                  'parallelism': 'dp%d' % world, 'name': name,
+                 'gemm_selection': 'blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)',
                  'learn_step': 'hip-graph replay' if args.use_graph else 'eager'},
       'roofline': roof,
   }
