@@ -61,12 +61,12 @@ class DDPGController(Controller):
     # creation order = the reference's, so equal seeds give equal initial weights
     self.actor = DDPGActorNet(obs_size, action_size, hidden).to(self.device)
     self.target_actor = DDPGActorNet(obs_size, action_size, hidden).to(self.device)
-    self._actor, self._target_actor = FlatParams(self.actor), FlatParams(self.target_actor)
+    self._actor, self._target_actor = FlatParams(self.actor, fresh_grads=True), FlatParams(self.target_actor)
     self._target_actor.copy_from(self._actor)
 
     self.critic = DDPGCriticNet(obs_size, action_size, hidden).to(self.device)
     self.target_critic = DDPGCriticNet(obs_size, action_size, hidden).to(self.device)
-    self._critic, self._target_critic = FlatParams(self.critic), FlatParams(self.target_critic)
+    self._critic, self._target_critic = FlatParams(self.critic, fresh_grads=True), FlatParams(self.target_critic)
     self._target_critic.copy_from(self._critic)
 
     self._sync = GradSync(process_group)

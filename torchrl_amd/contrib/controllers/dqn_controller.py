@@ -11,7 +11,7 @@ import torch
 from ...controllers import Controller
 from ...utils.schedule import ExpDecaySchedule
 from ... import functional as F
-from ..models import QNet
+from ..models import QNet, _fusable_stack
 from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
 
 
@@ -40,14 +40,18 @@ class DQNController(Controller):
 
     self.q_net = QNet(obs_size, action_size, hidden).to(self.device)
     self.target_q_net = QNet(obs_size, action_size, hidden).to(self.device)
-    self._q = FlatParams(self.q_net)
+    # stacks the whole-network kernels take (<= 64 wide) get their gradients written in place by the
+    # fused backward; the reference's 128-wide QNet goes through autograd, where fresh gradient
+    # tensors + one multi-tensor copy replace a fill and six accumulate launches per step
+    fusable = _fusable_stack(list(self.q_net.net)) is not None
+    self._q = FlatParams(self.q_net, fresh_grads=not fusable)
     self._target = FlatParams(self.target_q_net)
     self._target.copy_from(self._q)            # target_q_net.load_state_dict(q_net.state_dict())
     self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._q, self._target)
     self.q_net_optim = FlatAdam(self._q, lr=lr, grad_scale=self._sync.scale, device_state=graph)
-    for stack in (self.q_net.net,):     # one use per backward, zeroed grads: let the fused backward write .grad itself
-      stack.direct_grads = True
+    if fusable:     # one use per backward, zeroed grads: let the fused backward write .grad itself
+      self.q_net.net.direct_grads = True
     self._run = LearnRunner(self._learn_body, [self.q_net_optim], lambda: [], self.device, graph)
 
     self.double_dqn = double_dqn

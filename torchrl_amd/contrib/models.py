@@ -48,6 +48,26 @@ class _SplitKLinearFn(torch.autograd.Function):
     return gx, gw, gy.sum(0)
 
 
+class _LinearReluFn(torch.autograd.Function):
+  """relu(x W^T + b) as ONE BLAS call (bias and ReLU in the GEMM's epilogue); the backward is
+  what autograd runs for Linear + ReLU (mask, two products, bias sum).  Same values."""
+
+  @staticmethod
+  def forward(ctx, x, weight, bias):
+    y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+    ctx.save_for_backward(x, weight, y)
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    x, weight, y = ctx.saved_tensors
+    g = torch.ops.aten.threshold_backward(gy, y, 0.0)
+    gx = g @ weight if ctx.needs_input_grad[0] else None
+    gw = g.t() @ x if ctx.needs_input_grad[1] else None
+    gb = g.sum(0) if ctx.needs_input_grad[2] else None
+    return gx, gw, gb
+
+
 class SkinnyLinear(nn.Linear):
   """nn.Linear (same parameters, same init, same forward values) whose backward splits the
   batch reduction of the weight gradient; used for large device batches only."""
@@ -80,10 +100,29 @@ class _Mlp(nn.Sequential):
   FUSED_MIN_BATCH = 8192
   FUSED_MAX_WIDTH = 64
 
+  def _plain(self, x):
+    """The modules in order; on the device a Linear followed by ReLU is ONE BLAS call with the bias
+    and the ReLU in its epilogue (same values, one launch less per layer: the small-batch
+    learners are bound by their launch count)."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] < SkinnyLinear.SPLIT_MIN_BATCH
+            and _fused_mlp_enabled()):
+      return super().forward(x)
+    mods, i = list(self), 0
+    while i < len(mods):
+      m = mods[i]
+      if type(m) in (nn.Linear, SkinnyLinear) and m.bias is not None and i + 1 < len(mods) and \
+          isinstance(mods[i + 1], nn.ReLU):
+        x = _LinearReluFn.apply(x, m.weight, m.bias)
+        i += 2
+      else:
+        x = m(x)
+        i += 1
+    return x
+
   def forward(self, x):
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= self.FUSED_MIN_BATCH
             and _fused_mlp_enabled()):
-      return super().forward(x)
+      return self._plain(x)
     mods = list(self)
     whole = self._whole_net(mods, x)
     if whole is not None:

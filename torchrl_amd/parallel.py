@@ -49,6 +49,8 @@ class GradSync:
 
   def all_reduce(self, *flats):
     """Sum the gradients in place; returns the scale for the update (1 / world_size)."""
+    for f in flats:
+      f.collect_grads()
     if self.enabled:
       if self._host_staged and flats[0].grad.is_cuda:
         torch.cuda.current_stream(flats[0].device).synchronize()
