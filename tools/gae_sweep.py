@@ -54,15 +54,16 @@ def main():
   cp = [(lambda s=s: s[3][0].copy_(s[0])) for s in sets]
   us = graph_time_us(cp)
   print('torch copy r -> ret (8 B/elem): %.1f us  %.0f GB/s' % (us, 8 * T * N / us / 1e3))
-  configs = [(16, PF, d) for PF in (2, 3) for d in (0, 1, 2, 3, 8, 9, 10, 11)] + [(32, 2, 0), (32, 3, 0), (32, 3, 1)]
-  for E, PF, dbg in configs:
-    os.environ['TRL_GAE_TUNE'] = '%d,%d,%d' % (E, PF, dbg)
+  configs = [(16, PF, d, 2) for PF in (2, 3) for d in (0, 1, 2, 3, 8, 9, 10, 11)] + [(32, 2, 0, 2), (32, 3, 0, 2)]
+  configs += [(16, PF, d, 1) for PF in (2, 3, 4) for d in (0, 1, 11)]
+  for E, PF, dbg, U in configs:
+    os.environ['TRL_GAE_TUNE'] = '%d,%d,%d,%d' % (E, PF, dbg, U)
     try:
       us = graph_time_us([(lambda s=s: F.gae(s[0], s[1], s[2], 0.99, 0.95, out=s[3])) for s in sets])
     except Exception as e:  # noqa
       print('E=%2d PF=%d dbg=%2d  failed: %s' % (E, PF, dbg, str(e)[:80]))
       continue
-    print('E=%2d PF=%d dbg=%2d  %7.1f us %6.0f GB/s' % (E, PF, dbg, us, algo / us / 1e3), flush=True)
+    print('E=%2d PF=%d dbg=%2d U=%d  %7.1f us %6.0f GB/s' % (E, PF, dbg, U, us, algo / us / 1e3), flush=True)
   os.environ.pop('TRL_GAE_TUNE')
 
 

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_gae_tiled(const float *__restrict__ rew
 // delta and the chain wave reads the tile's done values straight from the raw ring (the slot of
 // the tile being scanned is the one kept alive as the next tile's halo):
 //   delta = (r + (gamma * v[t+1]) * (1 - d)) - v;   gae = delta + (gamma_lambda * (1 - d)) * gae
-template <int E, int PF, bool MASKED>
+template <int E, int PF, bool MASKED, int U = 2>
 __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ reward,
                                                   const float *__restrict__ value,
                                                   const float *__restrict__ done,
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
   // 2 = no output stores, 4 = no staging pass, 8 = no DMA
   constexpr int QPR = E / 4;        // quads (float4) per tile row
   constexpr int RPU = 256 / QPR;    // rows covered by one pass of the 256 worker lanes
-  constexpr int TT = 2 * RPU;       // rows per tile
+  constexpr int TT = U * RPU;       // rows per tile: U passes of the worker lanes (U = 1: half-size tiles,
+                                    // twice the stages, half the pipeline fill and drain)
   constexpr int PLANE = TT * E;     // 2048 floats
   constexpr int LD = E + 1;         // row stride of the staged value tile [t][env] (odd: the env-major
                                     // writer's column reads spread over the banks)
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
   constexpr int RPI = 256 / E;      // rows one 1 KiB DMA instruction covers
   constexpr int NP = MASKED ? 3 : 2;                // raw planes per tile: reward, value(, done)
   constexpr int SLOT = NP * PLANE;
-  constexpr int LPT = 4 * NP;                       // loads per tile per DMA wave
+  constexpr int IPW = 2 * U;                        // DMA instructions per plane per tile per wave
+  constexpr int LPT = IPW * NP;                     // loads per tile per DMA wave
   // one array: see cdna_hip_programming.md on a second __shared__ object beside a DMA ring
   __shared__ __attribute__((aligned(16))) float lds[NR * SLOT + NS * (E * TTP + TT * LD)];
   float *s_raw = lds;                               // [NR][NP][PLANE]  (reward plane, value plane, done plane)
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
 
   if (wave == 1 || wave == 2) {
     // ================================================================== DMA waves
-    const int dw = wave - 1;                       // owns instructions [dw*4, dw*4+4) of each plane
+    const int dw = wave - 1;                       // owns instructions [dw*IPW, (dw+1)*IPW) of each plane
     const int q = lane % QPR, rsub = lane / QPR;
     int envq = env0 + 4 * q;
     envq = envq < N ? envq : 0;                    // clamped: always a valid quad
@@ -179,8 +181,8 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
       const int lo = t_lo(jc), hi = t_hi(jc);
       float *slot = s_raw + (j % NR) * SLOT;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ins = dw * 4 + i;
+      for (int i = 0; i < IPW; ++i) {
+        const int ins = dw * IPW + i;
         int t = lo + ins * RPI + rsub;
         t = t < hi ? t : hi - 1;
         const int64_t g = (int64_t)t * N + envq;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
         const float *halo = s_raw + ((s + NR - 1) % NR) * SLOT + PLANE;   // tile s-1, row 0
         float *sd = s_d + (s % NS) * E * TTP, *sv = s_v + (s % NS) * TT * LD;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int tl = row0 + u * RPU;
           if (tl < rows) {
             const float4 r = *(const float4 *)(raw_r + tl * E + 4 * q);
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
         const float *sd = s_d + (jo % NS) * E * TTP, *sv = s_v + (jo % NS) * TT * LD;
         if (!out_nt) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          for (int u = 0; u < U; ++u) {
             const int tl = row0 + u * RPU;
             if (qlive && lo + tl < hi) {
               float rt[4], ad[4];
@@ -278,9 +280,9 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
           }
         } else {
           // env-major output: a lane takes 4 consecutive t of one env -> one 16 B store
-          constexpr int TQ = TT / 4;  // t-quads per env per tile; E * TQ == 512
+          constexpr int TQ = TT / 4;  // t-quads per env per tile; E * TQ == 256 * U
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          for (int u = 0; u < U; ++u) {
             const int i = m + u * 256;
             const int e = i / TQ, tq = i % TQ;
             const int tl = 4 * tq, t = lo + tl;
@@ -419,27 +421,37 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
   }
 }
 
-template <int E, int PF, bool MASKED>
+template <int E, int PF, bool MASKED, int U = 2>
 int launch_pipe(const float *reward, const float *value, const float *done, const float *bootstrap, int T, int N,
                 float gamma, float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
   const int ngroups = (int)trl_cdiv(N, E);
-  hipLaunchKernelGGL((k_gae_pipe<E, PF, MASKED>), dim3(ngroups), dim3(448), 0, st, reward, value, done, bootstrap, T,
+  hipLaunchKernelGGL((k_gae_pipe<E, PF, MASKED, U>), dim3(ngroups), dim3(448), 0, st, reward, value, done, bootstrap, T,
                      N, gamma, gl, out_nt, ngroups, returns, adv, dbg);
   TRL_CHECK_LAUNCH("trl_gae_reverse_scan");
   return TRL_OK;
 }
 
 // E and PF as run-time choices (0 = default heuristic); used by the dispatcher and the sweep tool
-int dispatch_pipe(int E, int PF, const float *reward, const float *value, const float *done, const float *bootstrap,
+int dispatch_pipe(int E, int PF, int U, const float *reward, const float *value, const float *done, const float *bootstrap,
                   int T, int N, float gamma, float gl, int out_nt, float *returns, float *adv, int dbg,
                   hipStream_t st) {
   if (E == 0) E = N > 256 * 32 ? 64 : (N > 256 * 16 ? 32 : 16);
   if (PF == 0) PF = 2;   // deeper prefetch measured no faster, cold or cache-resident (tools/gae_sweep.py)
+  // half-size tiles (64 rows at E = 16): twice the stages, half the pipeline fill and drain;
+  // 36.6 -> 32.5 us cold at T = 2048, N = 4096
+  if (U == 0) U = E == 16 ? 1 : 2;
   if (done) {            // masked extension: three planes per ring slot, the LDS holds PF = 2 at most
+    if (E == 16 && U == 1)
+      return launch_pipe<16, 2, true, 1>(reward, value, done, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
 #define TRL_PIPE_MCASE(e)  \
   if (E == e) return launch_pipe<e, 2, true>(reward, value, done, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
     TRL_PIPE_MCASE(16) TRL_PIPE_MCASE(32) TRL_PIPE_MCASE(64)
 #undef TRL_PIPE_MCASE
+  }
+  if (U == 1 && E == 16) {   // half-size tiles (tools/gae_sweep.py)
+    if (PF == 2) return launch_pipe<16, 2, false, 1>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
+    if (PF == 3) return launch_pipe<16, 3, false, 1>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
+    if (PF == 4) return launch_pipe<16, 4, false, 1>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
   }
 #define TRL_PIPE_CASE(e, pf)  \
   if (E == e && PF == pf)     \
@@ -492,9 +504,9 @@ extern "C" int trl_gae_reverse_scan(const float *reward, const float *value, con
   if (aligned && (!masked || (uintptr_t)done % 16 == 0)) {
     // Envs per workgroup: 16 (a 64 B row segment) while that gives at most one workgroup per
     // CU (the pipelined kernel holds most of a CU's LDS), then wider segments.
-    int E = 0, PF = 0, dbg = 0;
-    if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d", &E, &PF, &dbg);   // tools/gae_sweep.py
-    return dispatch_pipe(E, PF, reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma,
+    int E = 0, PF = 0, dbg = 0, U = 0;
+    if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d,%d", &E, &PF, &dbg, &U);   // tools/gae_sweep.py
+    return dispatch_pipe(E, PF, U, reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma,
                          gamma_lambda, out_layout, returns, adv, dbg, st);
   }
   return launch<16>(masked, reward, value, done, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
