@@ -33,7 +33,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 from torchrl_amd import functional as F  # noqa: E402
-from torchrl_amd.contrib.controllers import PPOController, DDPGController, DQNController  # noqa: E402
+from torchrl_amd.contrib.controllers import PPOController, A2CController, DDPGController, DQNController  # noqa: E402
 from torchrl_amd.utils.storage import TensorTupleDataset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
@@ -45,7 +45,7 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=None)
   ap.add_argument('--warmup', type=int, default=None)
-  ap.add_argument('--workload', default='ppo', choices=['ppo', 'ddpg', 'dqn_atari'])
+  ap.add_argument('--workload', default='ppo', choices=['ppo', 'a2c', 'ddpg', 'dqn_atari'])
   ap.add_argument('--T', type=int, default=2048)
   ap.add_argument('--N', type=int, default=4096)
   ap.add_argument('--hidden', default='64,64')
@@ -318,6 +318,46 @@ def cpu_baseline_ppo(info):
           'host_cpus': os.cpu_count()}
 
 
+
+# ------------------------------------------------------------------------------ A2C (the other half of configs[4])
+def bench_a2c(args, rank, world, dev):
+  """A2C on the same synthetic rollout shape (CartPole-shaped: obs 4, 2 discrete actions): one step =
+  value forward + return scan over [T, N], then ONE learn() over the whole rollout
+  (examples/a2c.py:38-53: a single batch per rollout)."""
+  T, N, obs_size, n_act = args.T, args.N, 4, 2
+  hidden = tuple(int(h) for h in args.hidden.split(','))
+  steps = args.steps if args.steps is not None else 10
+  warmup = args.warmup if args.warmup is not None else 2
+  torch.manual_seed(0)
+  ctl = A2CController(obs_size, n_act, gamma=0.99, lmbda=1.0, lr=1e-3, alpha=0.5, beta=1e-3, device=dev,
+                      hidden=hidden, graph=args.use_graph)
+  g = torch.Generator(device=dev).manual_seed(4321 + rank)
+  obs = torch.randn(T, N, obs_size, device=dev, generator=g)
+  action = torch.randint(0, n_act, (T, N), device=dev, generator=g).float()
+  reward = torch.randn(T, N, device=dev, generator=g)
+  last_next_obs = torch.randn(N, obs_size, device=dev, generator=g)
+  last_done = (torch.rand(N, device=dev, generator=g) < 0.01).float()
+  n = T * N
+  obs_em = obs.transpose(0, 1).reshape(n, obs_size).contiguous()
+  act_em = action.transpose(0, 1).reshape(n, 1).contiguous()
+
+  def step():
+    returns, _adv, _v = ctl.compute_return_batched(obs, reward, last_next_obs, last_done, env_major_out=True)
+    ctl.learn(obs_em, act_em, None, None, None, returns.reshape(n, 1))
+
+  dt = timed_steps(step, steps, warmup, world)
+  res = {
+      'metric': 'learner transitions/sec (A2C: return scan + loss + update)', 'value': round(n * steps * world / dt, 1),
+      'unit': 'transitions/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+      'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': 'a2c: T=%d, N_envs=%d per GPU, MLP %s, obs %d, %d actions, one learn() per rollout'
+                             % (T, N, args.hidden, obs_size, n_act),
+                 'parallelism': 'dp%d' % world,
+                 'learn_step': 'fused fwd+loss+bwd launch' if ctl._fused is not None else 'general path'},
+  }
+  return res, {}
+
 # ------------------------------------------------------------------------------ replay gathers
 def fill_ring(ds, n_rows, make_cols, chunk):
   for lo in range(0, n_rows, chunk):
@@ -480,6 +520,10 @@ def main():
   dev = torch.device('cuda', local)
   if args.workload == 'ppo':
     res, info = bench_ppo(args, rank, world, dev)
+  elif args.workload == 'a2c':
+    args.use_graph = args.graph == 'on'
+    res, info = bench_a2c(args, rank, world, dev)
+    args.no_cpu_baseline = True
   else:
     res, info = bench_offpolicy(args, rank, world, dev, atari=args.workload == 'dqn_atari')
   if rank == 0 and world == 1:
