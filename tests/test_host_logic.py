@@ -186,3 +186,23 @@ def test_gradient_allreduce_gloo_world2_equals_full_batch():
   flat.zero_grad()
   torch.nn.functional.mse_loss(net(x), y).backward()
   assert torch.allclose(flat.grad, g0, rtol=1e-5, atol=1e-7)
+
+
+def test_flat_params_fresh_grads_equal_accumulated():
+  """optim.FlatParams(fresh_grads=True): detached .grad + one multi-tensor copy gives the flat
+  gradient buffer that zero + autograd accumulation gives; unused parameters come out zero."""
+  import copy
+  from torchrl_amd.optim import FlatParams
+  torch.manual_seed(0)
+  net_a = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2), torch.nn.Linear(2, 2))
+  net_b = copy.deepcopy(net_a)
+  fa, fb = FlatParams(net_a), FlatParams(net_b, fresh_grads=True)
+  x = torch.randn(7, 3)
+  for f, net in ((fa, net_a), (fb, net_b)):
+    for _ in range(2):                       # second pass: no leftovers from the first
+      f.zero_grad()
+      net[2](net[1](net[0](x))).pow(2).sum().backward()      # the last Linear is unused
+      f.collect_grads()
+  assert torch.equal(fa.grad, fb.grad) and float(fa.grad.abs().max()) > 0
+  assert all(p.grad.data_ptr() == fb.grad.data_ptr() + 4 * off for p, off in zip(fb.params, fb.offsets))
+  assert float(fb.params[-1].grad.abs().max()) == 0.0

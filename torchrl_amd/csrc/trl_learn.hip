@@ -574,7 +574,6 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       put_tile(sG, g, half, r32);
       put_tile(sH, h1, half, r32);
       wave_lds_fence();
-      vdb1 += row_sum32(sG + lane * LDT);     // db1[lane] += sum over the strip's rows of g[lane][row]
       // rows in the order (j, half, i) -> row 8j + 4half + i: a lane's four steps are one 16 B read
       const float *ga = sG + r32 * LDT + 4 * half, *ha = sH + r32 * LDT + 4 * half;
       {
@@ -597,6 +596,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
           g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
         }
       }
+      vdb1 += row_sum32(sG + lane * LDT);     // db1[lane] += sum over the strip's rows of g[lane][row] (beside the MFMAs)
       f32x16 t[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -634,7 +634,6 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     // ---- layer 0 backward: dW0 += g x^T
     put_tile(sG, g, half, r32);
     wave_lds_fence();
-    vdb0 += row_sum32(sG + lane * LDT);
     PH(9);
     {
       const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
@@ -664,6 +663,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
         for (int kb = 0; kb < KB0; ++kb) xv[kb] = nx[kb];
       }
     }
+    vdb0 += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
     wave_lds_fence();     // the next strip overwrites sX / sG
     PH(3);
   }
