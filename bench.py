@@ -138,10 +138,10 @@ def kernel_time_us(launch, iters):
 
 
 def pmc_traffic(key):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json;
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01d_pmc_traffic.json;
   counters cannot be read from inside this process), or None when that launch was not profiled."""
   try:
-    with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r01d_pmc_traffic.json')) as f:
       return int(json.load(f)[key]['hbm_bytes'])
   except (OSError, KeyError, ValueError):
     return None
@@ -244,7 +244,7 @@ def bench_ppo(args, rank, world, dev):
   roof = roofline('k_gae_pipe', algo, us, '16 B per (t, env) step x T*N = %d steps per launch; inputs cold in '
                   'HBM (%d rotating buffer sets); cache-resident inputs: %.2f us = %.0f GB/s'
                   % (n, nsets, us_warm, algo / us_warm / 1e3),
-                  traffic_key='k_gae_pipe<16,3> T=2048 N=4096' if (T, N) == (2048, 4096) else None)
+                  traffic_key='k_gae_pipe T=2048 N=4096' if (T, N) == (2048, 4096) else None)
   roof['copy_ceiling'] = {'GB/s': round(algo / us_copy / 1e3, 1), 'us': round(us_copy, 2),
                           'note': 'torch device copy of the same bytes over the same cold buffer sets, same process'}
   roof['frac_of_copy_ceiling'] = round(us_copy / us, 4)
