@@ -169,3 +169,42 @@ def test_fused_a2c_learn_matches_oracle(obs_size, A, hidden, B):
   got_w = ctl._flat.dense().cpu()
   assert float((got_w - exp_w).abs().max()) <= 2.5e-3
   assert float(((got_w - exp_w).abs() > 1e-5).float().mean()) < 0.02
+
+
+def _random_shapes(n, seed):
+  rs = np.random.RandomState(seed)
+  out = []
+  for _ in range(n):
+    depth = int(rs.choice([2, 3]))
+    hidden = tuple(int(rs.randint(1, 65)) for _ in range(depth - 1))
+    A = int(rs.randint(1, 3 if depth == 3 else 5))
+    out.append((int(rs.randint(1, 65)), A, hidden, int(rs.randint(256, 3000))))
+  return out
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B', _random_shapes(14, 2024))
+def test_fused_learn_random_shapes(obs_size, A, hidden, B):
+  """Seeded random widths / depths / batch sizes (padding, ragged tails, every template variant):
+  gradients of the whole-step kernel vs torch-CPU autograd of the same loss, no clamp in the way."""
+  torch.manual_seed(B + obs_size)
+  ctl = PPOController(obs_size, A, lr=1e-3, alpha=0.5, beta=1e-2, max_grad_norm=1e9, device=DEV, hidden=hidden)
+  assert ctl._fused is not None
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  obs, act, ret, adv, g = _batch(obs_size, A, B, B)
+  with torch.no_grad():
+    mean = ref.actor(obs)
+    old = torch.distributions.Normal(mean, ref.log_std.exp().expand_as(mean)).log_prob(act)
+    old = old + 0.3 * torch.randn(B, A, generator=g)
+  value, mean = ref.critic(obs), ref.actor(obs)
+  actor, critic, ent = loss_oracle.ppo_losses(value, mean, ref.log_std, act, old, adv, ret, 0.2)
+  (actor + 0.5 * critic - 1e-2 * ent).backward()
+  exp_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+  losses = ctl._fused(obs.to(DEV), act.to(DEV), ret.to(DEV), old.to(DEV), adv.to(DEV), 0.2, 0.5, 1e-2).cpu()
+  for e, v in zip((actor, critic, ent), losses[:3]):
+    assert abs(float(v) - float(e.detach())) <= 2e-6 * abs(float(e.detach())) + 3e-7, (float(v), float(e.detach()))
+  got_grad = ctl._flat.dense(grad=True).cpu()
+  np.testing.assert_allclose(got_grad.numpy(), exp_grad.numpy(), rtol=2e-4, atol=3e-5 * float(exp_grad.abs().max()))
+  # and the forward-only kernel on the same shapes
+  v2, m2, _ = ctl._fused.forward(obs.to(DEV))
+  torch.testing.assert_close(v2.cpu(), value.detach().view(-1), rtol=1e-5, atol=3e-6)
+  torch.testing.assert_close(m2.cpu(), mean.detach(), rtol=1e-5, atol=3e-6)
