@@ -61,8 +61,8 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                  help='HIP-graph replay of learn(); auto = off for ppo (its whole step is one fused launch + a '
-                       'reduce, eager issue keeps up), on for the off-policy loops')
+                  help='HIP-graph replay of learn(); auto = off for ppo / a2c / ddpg (their whole step is a handful of '
+                       'fused launches, eager issue keeps up), on for dqn_atari (BLAS + autograd path)')
   ap.add_argument('--no-graph', action='store_true', help='same as --graph off')
   return ap.parse_args()
 
@@ -468,7 +468,9 @@ def bench_offpolicy(args, rank, world, dev, atari):
                  'philox on the device (throughput mode, not index-identical to torch.randperm)',
                  'parallelism': 'dp%d' % world, 'name': name,
                  'gemm_selection': 'blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)',
-                 'learn_step': 'hip-graph replay' if args.use_graph else 'eager'},
+                 'learn_step': 'hip-graph replay' if args.use_graph else
+                 ('eager, whole step in %d launches (csrc/trl_offpolicy.hip)' % (6 if atari else 11)
+                  if getattr(ctl, '_fused', None) is not None else 'eager')},
       'roofline': roof,
   }
   return res, dict(cap=cap, B=B, atari=atari)
@@ -515,7 +517,7 @@ def main():
   args = parse()
   if args.no_graph:
     args.graph = 'off'
-  args.use_graph = args.graph == 'on' or (args.graph == 'auto' and args.workload != 'ppo')
+  args.use_graph = args.graph == 'on' or (args.graph == 'auto' and args.workload == 'dqn_atari')
   rank, local, world = setup_dist(args)
   dev = torch.device('cuda', local)
   if args.workload == 'ppo':

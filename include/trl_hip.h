@@ -310,6 +310,42 @@ int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor,
                           const float *obs, const float *action, int64_t B, int32_t A, float *value, float *mean,
                           float *logp, void *stream);
 
+/* ------------------------------------------------------------------ fused off-policy learner steps (a-2 + a-4)
+ * DDPGController.learn (ddpg_controller.py:101-128) as 11 launches (csrc/trl_offpolicy.hip): the five
+ * forward passes (actor(obs), critic(obs, actor(obs)), critic(obs, action), target_critic(next_obs,
+ * target_actor(next_obs)); models.py:27-81), y = reward + (1 - done) * gamma * target_q, the two
+ * losses, the backward of -mean Q through the critic into the actor's parameters only (the reference
+ * discards what that pass leaves in the critic, :116-118) and of the critic loss into the critic's,
+ * both Adam steps, and the Polyak averages of both targets (:42-57, :120-121) on the updated weights.
+ *   Networks: two hidden ReLU layers (depth 3), hidden widths multiples of 16 up to 1024;
+ *   actor obs -> A (tanh), critic [obs | action] -> 1; targets shaped like their online nets.
+ *   obs, next_obs [B, S]; action [B, A]; reward, done [B]; B a multiple of 16, <= 4096.
+ *   losses_out[0] = actor loss, [1] = critic loss.
+ *   actor_opt / critic_opt: the flat buffers of each optimizer (see trl_adam_args); the networks'
+ *   parameters must be views into `param`, their gradients are written at the same offsets of `grad`.
+ *   step > 0: Adam is applied where each gradient tile is produced, then
+ *   target <- tau * param + (1 - tau) * target into target_*_flat (same layout as `param`).
+ *   step == 0 (both): gradients only -- for an all-reduce between backward and update.
+ * `ws`: trl_ddpg_learn_workspace_bytes() bytes of device scratch, 16 B aligned. */
+int64_t trl_ddpg_learn_workspace_bytes(const trl_mlp_desc *actor, const trl_mlp_desc *critic, int64_t B);
+int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_desc *critic, const trl_mlp_desc *target_actor,
+                         const trl_mlp_desc *target_critic, const float *obs, const float *action,
+                         const float *reward, const float *next_obs, const float *done, int64_t B, double gamma,
+                         int32_t kind, double huber_delta, float *losses_out, const trl_adam_args *actor_opt,
+                         const trl_adam_args *critic_opt, float *target_actor_flat, float *target_critic_flat,
+                         double tau, void *ws, void *stream);
+
+/* DQNController.learn up to the optimizer step (dqn_controller.py:61-83; the periodic hard sync
+ * of :85-86 stays trl_polyak with tau = 1) as 6 launches: q_net(obs), target_net(next_obs) and, for
+ * Double-DQN, q_net(next_obs) (QNet, models.py:6-24); the TD target and loss (trl_td_loss); the
+ * backward into q_net; Adam.  Same network / batch limits as above; action [B] holds the index as
+ * f32.  loss_out[0] = td loss.  opt->step == 0: gradients only. */
+int64_t trl_dqn_learn_workspace_bytes(const trl_mlp_desc *q_net, int64_t B);
+int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const float *obs,
+                        const float *action, const float *reward, const float *next_obs, const float *done,
+                        int64_t B, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
+                        float *loss_out, const trl_adam_args *opt, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

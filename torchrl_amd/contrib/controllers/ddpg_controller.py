@@ -1,4 +1,6 @@
 """DDPG controller on the fused critic-target kernel (reference: ddpg_controller.py)."""
+import os
+
 import numpy as np
 import torch
 
@@ -77,6 +79,15 @@ class DDPGController(Controller):
                             lambda: [self._target_actor.data, self._target_critic.data], self.device,
                             graph and not self._sync.enabled)
 
+    # the whole step as 11 launches (csrc/trl_offpolicy.hip) for two-hidden-layer stacks, eager mode;
+    # TRL_FUSED_LEARN=0 keeps the autograd path
+    self._fused = None
+    if self.device.type == 'cuda' and not graph and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+      lins = [[m for m in net.net if isinstance(m, torch.nn.Linear)]
+              for net in (self.actor, self.critic, self.target_actor, self.target_critic)]
+      if F.FusedDdpgLearn.supports(*lins):
+        self._fused = F.FusedDdpgLearn(*lins, self._actor, self._critic, self._target_actor, self._target_critic)
+
     self.gamma = gamma
     self.tau = tau
     self.n_reset_interval = n_reset_interval
@@ -114,6 +125,19 @@ class DDPGController(Controller):
     return action
 
   def _learn_body(self, obs, action, reward, next_obs, done):
+    if self._fused is not None and self._fused.usable(obs):
+      solo = not self._sync.enabled
+      losses = self._fused(obs, action, reward, next_obs, done, self.gamma, self.tau, self.actor_optim,
+                           self.critic_optim, update=solo, huber_delta=self.huber_delta)
+      if not solo:      # gradients only: all-reduce, then the flat-buffer updates
+        self._sync.all_reduce(self._actor)
+        self.actor_optim.step()
+        self._sync.all_reduce(self._critic)
+        self.critic_optim.step()
+        self._target_actor.polyak_from(self._actor, self.tau)
+        self._target_critic.polyak_from(self._critic, self.tau)
+      return losses
+
     actor_loss = -self.critic(obs, self.actor(obs)).mean()
 
     current_q = self.critic(obs, action)

@@ -5,6 +5,8 @@ with torch matmuls and hands them to one HIP kernel that forms the (double) targ
 and dL/dQ in a single pass (csrc/trl_loss.hip: k_td_loss); Adam and the hard target sync are
 one launch each over flat parameter buffers.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -54,6 +56,14 @@ class DQNController(Controller):
       self.q_net.net.direct_grads = True
     self._run = LearnRunner(self._learn_body, [self.q_net_optim], lambda: [], self.device, graph)
 
+    # the step up to Adam as 6 launches (csrc/trl_offpolicy.hip) for two-hidden-layer Q-networks up
+    # to 1024 wide / fan-in, eager mode; TRL_FUSED_LEARN=0 keeps the autograd path
+    self._fused = None
+    if self.device.type == 'cuda' and not graph and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+      lins = [[m for m in net.net if isinstance(m, torch.nn.Linear)] for net in (self.q_net, self.target_q_net)]
+      if F.FusedDqnLearn.supports(*lins):
+        self._fused = F.FusedDqnLearn(*lins, self._q, self._target)
+
     self.double_dqn = double_dqn
     self.gamma = gamma
     self.n_update_interval = n_update_interval
@@ -81,6 +91,10 @@ class DQNController(Controller):
       return torch.where(explore, uniform, greedy)
 
   def _learn_body(self, obs, action, reward, next_obs, done):
+    if self._fused is not None and self._fused.usable(obs):
+      return self._fused(obs, action, reward, next_obs, done, self.gamma, self.q_net_optim,
+                         double_dqn=self.double_dqn, update=not self._sync.enabled,
+                         huber_delta=self.huber_delta)[0]
     q = self.q_net(obs)
     with torch.no_grad():
       q_next_target = self.target_q_net(next_obs)

@@ -52,6 +52,22 @@ __device__ __forceinline__ float trl_block_sum(float v, float *red) {
   return s;
 }
 
+// ---- one element of the TD / critic loss and its derivative: squared error (dqn_controller.py:77-78,
+// ddpg_controller.py:112) or Huber (extension)
+__device__ __forceinline__ float trl_loss_elem(float td, int kind, float delta, float *g) {
+  if (kind == TRL_LOSS_MSE) {
+    *g = 2.0f * td;  // pow(2) backward: 2 * td
+    return td * td;
+  }
+  const float a = fabsf(td);
+  if (a <= delta) {
+    *g = td;
+    return 0.5f * td * td;
+  }
+  *g = td > 0.f ? delta : -delta;
+  return delta * (a - 0.5f * delta);
+}
+
 // ---- torch.optim.Adam's default single-tensor update on one element, shared by the flat-buffer
 // update kernels (trl_loss.hip) and the fused learner step's reduce launch (trl_learn.hip).
 struct TrlAdamScalars {

@@ -36,17 +36,7 @@ __device__ __forceinline__ float sum_partials(const float *ws, int nb, int K, in
 }
 
 __device__ __forceinline__ float loss_elem(float td, int kind, float delta, float *g) {
-  if (kind == TRL_LOSS_MSE) {
-    *g = 2.0f * td;  // pow(2) backward: 2 * td
-    return td * td;
-  }
-  const float a = fabsf(td);
-  if (a <= delta) {
-    *g = td;
-    return 0.5f * td * td;
-  }
-  *g = td > 0.f ? delta : -delta;
-  return delta * (a - 0.5f * delta);
+  return trl_loss_elem(td, kind, delta, g);
 }
 
 // ------------------------------------------------------------------------------ TD

@@ -1,0 +1,657 @@
+// Whole learner step of the small-batch off-policy controllers as a short chain of launches.
+//   DDPGController.learn   ddpg_controller.py:101-128 (+ polyak_average_ :42-57)
+//   DQNController.learn    dqn_controller.py:61-83
+// on the reference networks (models.py: DDPGActorNet :27-53, DDPGCriticNet :56-81, QNet :6-24:
+// two hidden ReLU layers, 128-256 wide) at the reference batch sizes (32-256 rows).
+//
+// At these sizes a step is ~170 MFLOP: nothing is bound by arithmetic or by HBM (every operand is
+// L2-resident), the step is bound by HOW MANY dependent launches it takes.  Built from BLAS calls
+// and elementwise kernels it is ~70 launches; here it is 11 (DDPG) / 6 (DQN):
+//   * one launch = one *phase*: up to 4 independent matrix products of the step that have the same
+//     dependency depth (e.g. layer 1 of actor, target actor and critic), each cut into 16x16 output
+//     tiles, one workgroup per tile, so a phase fills 100-400 CUs;
+//   * a workgroup's 4 waves split the reduction dimension (split-K), issue all their operand loads
+//     up front, run v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate) and add their four
+//     partial tiles in a fixed order through LDS: the critical path of a phase is one L2 round trip
+//     + <= 16 MFMAs + one LDS exchange;
+//   * everything elementwise rides in a product's operand fetch or epilogue: bias / ReLU / tanh,
+//     the input concatenation [obs | action] of the critic, the ReLU / tanh masks of the backward,
+//     the last layer's backward (a masked outer product, formed on the fly as the next product's
+//     operand instead of being materialised), bias gradients (column sums of the same operand), and
+//     the optimizer: a weight-gradient tile is consumed where it is produced -- Adam on the tile's
+//     parameters, then the Polyak average into the target network's same tile.
+// Products whose weights are still read later in the chain are ordered before the launch that
+// updates them; nothing inside one launch reads a parameter another workgroup of it writes.
+// Reductions have a fixed order, so a step is bitwise reproducible run to run.
+#include <math.h>
+#include <string.h>
+
+#include "trl_common.h"
+
+namespace {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+enum { T_FWD = 0, T_DX = 1, T_DW = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+enum { UPD_GRAD = 0, UPD_ADAM = 1, UPD_ADAM_POLYAK = 2 };
+constexpr int MAX_TILES = 4;
+
+// A gradient operand G [B, Kg]: materialised (g != NULL), or the backward of the layer above taken
+// on the fly:  G[i, k] = (h[i, k] > 0) * sum_a seed[i, a] * w2[a, k]   (h = this layer's ReLU output,
+// w2 [As, Kg] = the next layer's weight, seed [B, As] = the gradient at that layer's output, or the
+// constant cseed when seed == NULL).
+struct Grad {
+  const float *g;
+  const float *seed;
+  const float *w2;
+  const float *h;
+  int ld;
+  int As;
+  float cseed;
+};
+
+struct Tile {
+  int type;
+  int M, N, K;        // output M x N, reduction length K
+  int tiles_n;
+  int wg0;            // first workgroup of this problem in the launch
+  int fast;           // FWD: 16 B operand loads (single source, K % 4 == 0, aligned bases)
+  int act;            // FWD: activation; DX: the mask applied to the product
+  // FWD: y[B, N] = act([x1 | x2][B, K1 + K2] @ w[N, K]^T + b);   DW: X = [x1 | x2] [B, N]
+  const float *x1, *x2;
+  int K1, K2;
+  const float *w;     // FWD: [N, K];  DX: [K, ldw], columns woff .. woff + N - 1 are used
+  int ldw, woff;
+  const float *b;
+  float *y;           // FWD / DX output [B, ldy]
+  int ldy;
+  // DX: y[B, N] = (G[B, K] @ w[K, woff : woff + N]) * mask(hin);  gout: optional copy of G [B, K]
+  // DW: dW[M, N] = G[B, M]^T @ X[B, N]  (K = B);  db[M] = column sums of G
+  Grad G;
+  const float *hin;
+  int ldhin;
+  float *gout;
+  int64_t w_off, b_off;  // offsets of the weight / bias in the optimizer's flat buffers
+  int upd;               // which Update of the launch
+};
+
+struct Update {
+  float *param, *grad, *m, *v, *target;
+  TrlAdamScalars s;
+  float tau, omt;
+  int mode;
+};
+
+struct PhaseArgs {
+  Tile t[MAX_TILES];
+  Update u[2];
+  int nt;
+};
+
+__device__ __forceinline__ f4v ld4(const float *p) { return *reinterpret_cast<const f4v *>(p); }
+
+__device__ __forceinline__ f4v grad_row4(const Grad &G, int i, int k, int Kg, bool virt) {
+  if (!virt) return ld4(G.g + (size_t)i * G.ld + k);
+  const f4v h = ld4(G.h + (size_t)i * Kg + k);
+  f4v acc = {0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < G.As; ++a) {
+    const float s = G.seed ? G.seed[(size_t)i * G.As + a] : G.cseed;
+    const f4v w = ld4(G.w2 + (size_t)a * Kg + k);
+    acc += s * w;
+  }
+  f4v r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) r[c] = h[c] > 0.f ? acc[c] : 0.f;
+  return r;
+}
+
+__device__ __forceinline__ float grad_at(const Grad &G, int i, int m, int Kg, bool virt) {
+  if (!virt) return G.g[(size_t)i * G.ld + m];
+  const float h = G.h[(size_t)i * Kg + m];
+  float acc = 0.f;
+  for (int a = 0; a < G.As; ++a) {
+    const float s = G.seed ? G.seed[(size_t)i * G.As + a] : G.cseed;
+    acc += s * G.w2[(size_t)a * Kg + m];
+  }
+  return h > 0.f ? acc : 0.f;
+}
+
+// X = [x1 | x2] at (row i, column k), k < K1 + K2
+__device__ __forceinline__ float cat_at(const Tile &T, int i, int k) {
+  const float *p = k < T.K1 ? T.x1 + (size_t)i * T.K1 + k : T.x2 + (size_t)i * T.K2 + (k - T.K1);
+  return *p;
+}
+
+// One wave's share [kb, ke) of the reduction: operand quads for 64 k's are fetched before the 16
+// MFMAs that consume them.  Lane (r = lane & 15, q = lane >> 4) feeds row r of A and column r of B at
+// the four k's kk .. kk + 3, kk = kc + 16 u + 4 q -- the same k's on both sides, which is all the
+// instruction needs (it sums over its k slots; which k sits in which slot is free).
+template <class LA, class LB>
+__device__ __forceinline__ f4v mma_range(int kb, int ke, int q, LA load_a, LB load_b) {
+  f4v acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kc = kb; kc < ke; kc += 64) {
+    f4v a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = kc + 16 * u + 4 * q;
+      a[u] = load_a(kk);
+      b[u] = load_b(kk);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b[u][c], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void apply_update(const Update &U, int64_t off, float g) {
+  U.grad[off] = g;
+  if (U.mode >= UPD_ADAM) {
+    trl_adam_elem(U.param + off, U.grad + off, U.m + off, U.v + off, U.s);
+    if (U.mode == UPD_ADAM_POLYAK)
+      U.target[off] = __fadd_rn(__fmul_rn(U.tau, U.param[off]), __fmul_rn(U.omt, U.target[off]));
+  }
+}
+
+template <int TYPE, bool FLAG>   // FLAG: FWD -> fast loads;  DX / DW -> G is taken on the fly
+__device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int tn, int kb, int ke, int r, int q) {
+  if (TYPE == T_FWD) {
+    const int i = m0 + r;                    // batch row (B % 16 == 0: always valid)
+    const int n = n0 + r, nc = n < T.N ? n : 0;
+    const int K = T.K;
+    if (FLAG) {
+      const float *xa = T.x1 + (size_t)i * K;
+      const float *wb = T.w + (size_t)nc * K;
+      const bool nok = n < T.N;
+      return mma_range(kb, ke, q,
+          [&](int kk) { const bool ok = kk < ke; f4v v = ld4(xa + (ok ? kk : 0)); return ok ? v : f4v{0.f, 0.f, 0.f, 0.f}; },
+          [&](int kk) { const bool ok = kk < ke && nok; f4v v = ld4(wb + (kk < ke ? kk : 0)); return ok ? v : f4v{0.f, 0.f, 0.f, 0.f}; });
+    }
+    return mma_range(kb, ke, q,
+        [&](int kk) {
+          f4v v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = cat_at(T, i, ok ? k : 0); v[c] = ok ? x : 0.f; }
+          return v;
+        },
+        [&](int kk) {
+          f4v v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = T.w[(size_t)nc * K + (ok ? k : 0)]; v[c] = (ok && n < T.N) ? x : 0.f; }
+          return v;
+        });
+  }
+  if (TYPE == T_DX) {
+    const int i = m0 + r;
+    const int n = n0 + r, nc = n < T.N ? n : 0;
+    const bool wr = T.gout != nullptr && tn == 0;
+    return mma_range(kb, ke, q,
+        [&](int kk) {
+          const bool ok = kk < ke;
+          f4v v = grad_row4(T.G, i, ok ? kk : 0, T.K, FLAG);
+          if (wr && ok) *reinterpret_cast<f4v *>(T.gout + (size_t)i * T.K + kk) = v;
+          return ok ? v : f4v{0.f, 0.f, 0.f, 0.f};
+        },
+        [&](int kk) {
+          f4v v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = T.w[(size_t)(ok ? k : 0) * T.ldw + T.woff + nc]; v[c] = (ok && n < T.N) ? x : 0.f; }
+          return v;
+        });
+  }
+  // T_DW: rows of the product = output features m, columns = input features n, reduction over the batch
+  const int m = m0 + r, mc = m < T.M ? m : 0;
+  const int n = n0 + r, nc = n < T.N ? n : 0;
+  return mma_range(kb, ke, q,
+      [&](int kk) {
+        f4v v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = grad_at(T.G, ok ? i : 0, mc, T.M, FLAG); v[c] = (ok && m < T.M) ? x : 0.f; }
+        return v;
+      },
+      [&](int kk) {
+        f4v v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = cat_at(T, ok ? i : 0, nc); v[c] = (ok && n < T.N) ? x : 0.f; }
+        return v;
+      });
+}
+
+__global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
+  __shared__ float red[4][256];
+  const int wg = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TILES; ++i)
+    if (i < P.nt && wg >= P.t[i].wg0) pi = i;
+  const Tile &T = P.t[pi];
+  const int tl = wg - T.wg0;
+  const int tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, r = lane & 15, q = lane >> 4;
+  const int Kq = (T.K + 63) / 64 * 16;      // per-wave share of the reduction, a multiple of 16
+  const int kb = w * Kq;
+  const int ke = min(T.K, kb + Kq);
+  const bool virt = T.G.g == nullptr;
+
+  f4v acc;
+  if (T.type == T_FWD)
+    acc = T.fast ? tile_product<T_FWD, true>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_FWD, false>(T, m0, n0, tn, kb, ke, r, q);
+  else if (T.type == T_DX)
+    acc = virt ? tile_product<T_DX, true>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DX, false>(T, m0, n0, tn, kb, ke, r, q);
+  else
+    acc = virt ? tile_product<T_DW, true>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DW, false>(T, m0, n0, tn, kb, ke, r, q);
+
+  // lane (r, q), register c holds element (row 4 q + c, column r) of the wave's partial tile
+#pragma unroll
+  for (int c = 0; c < 4; ++c) red[w][(4 * q + c) * 16 + r] = acc[c];
+  __syncthreads();
+  float v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+  const int row = t >> 4, col = t & 15;
+  const int m = m0 + row, n = n0 + col;
+
+  if (T.type == T_FWD) {
+    if (n < T.N) {
+      v += T.b[n];
+      if (T.act == ACT_RELU) v = fmaxf(v, 0.f);
+      else if (T.act == ACT_TANH) v = tanhf(v);
+      T.y[(size_t)m * T.ldy + n] = v;
+    }
+    return;
+  }
+  if (T.type == T_DX) {
+    if (n < T.N) {
+      if (T.act != ACT_NONE) {
+        const float hv = T.hin[(size_t)m * T.ldhin + n];
+        v = T.act == ACT_RELU ? (hv > 0.f ? v : 0.f) : v * (1.0f - hv * hv);
+      }
+      T.y[(size_t)m * T.ldy + n] = v;
+    }
+    return;
+  }
+  const Update &U = P.u[T.upd];
+  if (m < T.M && n < T.N) apply_update(U, T.w_off + (int64_t)m * T.N + n, v);
+  if (tn != 0) return;
+  // bias gradient of rows m0 .. m0 + 15: column sums of G over the batch, 16 row segments per column
+  __syncthreads();
+  {
+    const int mm = m0 + col, mc = mm < T.M ? mm : 0;
+    const int rps = T.K / 16;
+    float s = 0.f;
+    for (int i = row * rps; i < (row + 1) * rps; ++i) s += grad_at(T.G, i, mc, T.M, virt);
+    red[0][t] = s;
+  }
+  __syncthreads();
+  if (t < 16 && m0 + t < T.M) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[0][g * 16 + t];
+    apply_update(U, T.b_off + m0 + t, s);
+  }
+}
+
+// y = reward + (1 - done) * gamma * next_q;  critic loss = mean(l(cur - y));  actor loss = -mean(q_pi)
+// (ddpg_controller.py:105-112), and the gradient of the critic loss at cur.  One workgroup.
+__global__ __launch_bounds__(256) void k_ddpg_losses(const float *__restrict__ cur, const float *__restrict__ q_pi,
+                                                     const float *__restrict__ nq, const float *__restrict__ reward,
+                                                     const float *__restrict__ done, int B, float gamma, int kind,
+                                                     float hdelta, float *__restrict__ dcur,
+                                                     float *__restrict__ losses_out) {
+  __shared__ float red[4];
+  const float invB = 1.0f / (float)B;
+  float s_c = 0.f, s_a = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float y = reward[b] + ((1.0f - done[b]) * gamma) * nq[b];
+    const float td = cur[b] - y;
+    float g;
+    s_c += trl_loss_elem(td, kind, hdelta, &g);
+    dcur[b] = invB * g;
+    s_a += q_pi[b];
+  }
+  s_c = trl_block_sum<4>(s_c, red);
+  s_a = trl_block_sum<4>(s_a, red);
+  if (threadIdx.x == 0) {
+    losses_out[0] = -(s_a * invB);
+    losses_out[1] = s_c * invB;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct Phase {
+  PhaseArgs a;
+  int wgs;
+  Phase() : wgs(0) { memset(&a, 0, sizeof(a)); }
+  Tile &add(int type, int M, int N, int K, int tiles_m) {
+    Tile &T = a.t[a.nt++];
+    T.type = type;
+    T.M = M;
+    T.N = N;
+    T.K = K;
+    T.tiles_n = (N + 15) / 16;
+    T.wg0 = wgs;
+    wgs += tiles_m * T.tiles_n;
+    return T;
+  }
+};
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// y[B, N] = act([x1 | x2] @ w^T + b)
+void add_fwd(Phase &ph, int B, const float *x1, int K1, const float *x2, int K2, const float *w, const float *b, int N,
+             int act, float *y) {
+  Tile &T = ph.add(T_FWD, B, N, K1 + K2, B / 16);
+  T.x1 = x1; T.K1 = K1; T.x2 = x2; T.K2 = K2;
+  T.w = w; T.ldw = K1 + K2; T.b = b; T.act = act; T.y = y; T.ldy = N;
+  T.fast = K2 == 0 && K1 % 4 == 0 && aligned16(x1) && aligned16(w);
+}
+
+Grad g_virtual(const float *seed, float cseed, int As, const float *w2, const float *h) {
+  Grad G;
+  G.g = nullptr; G.ld = 0; G.seed = seed; G.cseed = cseed; G.As = As; G.w2 = w2; G.h = h;
+  return G;
+}
+
+Grad g_material(const float *g, int ld) {
+  Grad G;
+  G.g = g; G.ld = ld; G.seed = nullptr; G.cseed = 0.f; G.As = 0; G.w2 = nullptr; G.h = nullptr;
+  return G;
+}
+
+// y[B, N] = (G[B, K] @ w[K, woff : woff + N]) * mask(hin)
+void add_dx(Phase &ph, int B, Grad G, int K, const float *w, int ldw, int woff, int N, int act, const float *hin,
+            int ldhin, float *y, float *gout) {
+  Tile &T = ph.add(T_DX, B, N, K, B / 16);
+  T.G = G; T.w = w; T.ldw = ldw; T.woff = woff; T.act = act; T.hin = hin; T.ldhin = ldhin; T.y = y; T.ldy = N;
+  T.gout = gout;
+}
+
+// dW[M, N] = G[B, M]^T @ [x1 | x2][B, N], db[M] = column sums of G; consumed by Update `upd`
+void add_dw(Phase &ph, int B, Grad G, int M, const float *x1, int K1, const float *x2, int K2, int64_t w_off,
+            int64_t b_off, int upd) {
+  Tile &T = ph.add(T_DW, M, K1 + K2, B, (M + 15) / 16);
+  T.G = G; T.x1 = x1; T.K1 = K1; T.x2 = x2; T.K2 = K2; T.w_off = w_off; T.b_off = b_off; T.upd = upd;
+}
+
+int launch(Phase &ph, hipStream_t st, const char *what) {
+  hipLaunchKernelGGL(k_phase, dim3(ph.wgs), dim3(256), 0, st, ph.a);
+  TRL_CHECK_LAUNCH(what);
+  return TRL_OK;
+}
+
+Update make_update(const trl_adam_args *o, float *target, double tau) {
+  Update U;
+  memset(&U, 0, sizeof(U));
+  U.param = o->param; U.grad = o->grad; U.m = o->exp_avg; U.v = o->exp_avg_sq; U.target = target;
+  U.mode = UPD_GRAD;
+  if (o->step > 0) {
+    U.s = trl_adam_scalars(o->lr, o->beta1, o->beta2, o->eps, o->step, o->grad_scale, o->clip_value);
+    U.mode = target ? UPD_ADAM_POLYAK : UPD_ADAM;
+    U.tau = (float)tau;
+    U.omt = (float)(1.0 - tau);
+  }
+  return U;
+}
+
+constexpr int MAX_WIDTH = 1024, MAX_BATCH = 4096;
+
+int check_net(const char *fn, const char *name, const trl_mlp_desc *n, const trl_adam_args *opt) {
+  TRL_REQUIRE(n != nullptr, "%s: %s is NULL", fn, name);
+  TRL_REQUIRE(n->depth == 3, "%s: %s must have two hidden layers (depth 3), got depth %d", fn, name, n->depth);
+  TRL_REQUIRE(n->dims[0] >= 1 && n->dims[0] <= MAX_WIDTH && n->dims[3] >= 1 && n->dims[3] <= MAX_WIDTH,
+              "%s: %s fan-in / fan-out out of range", fn, name);
+  for (int l = 1; l <= 2; ++l)
+    TRL_REQUIRE(n->dims[l] >= 16 && n->dims[l] % 16 == 0 && n->dims[l] <= MAX_WIDTH,
+                "%s: %s hidden width %d must be a multiple of 16 in [16, %d]", fn, name, n->dims[l], MAX_WIDTH);
+  for (int l = 0; l < 3; ++l) {
+    TRL_REQUIRE(n->w[l] != nullptr && n->b[l] != nullptr, "%s: %s has a NULL parameter", fn, name);
+    TRL_REQUIRE(aligned16(n->w[l]), "%s: %s weights must be 16 B aligned", fn, name);
+    if (opt) {
+      const int64_t wo = n->w[l] - opt->param, bo = n->b[l] - opt->param;
+      TRL_REQUIRE(wo >= 0 && wo + (int64_t)n->dims[l + 1] * n->dims[l] <= opt->n && bo >= 0 && bo + n->dims[l + 1] <= opt->n,
+                  "%s: %s parameters must lie inside the optimizer's flat buffer", fn, name);
+    }
+  }
+  return TRL_OK;
+}
+
+bool same_shape(const trl_mlp_desc *a, const trl_mlp_desc *b) {
+  return a->depth == b->depth && a->dims[0] == b->dims[0] && a->dims[1] == b->dims[1] && a->dims[2] == b->dims[2] &&
+         a->dims[3] == b->dims[3];
+}
+
+struct Carve {
+  float *base;
+  size_t off;
+  float *take(size_t n) {
+    float *p = base ? base + off : nullptr;
+    off += (n + 63) / 64 * 64;
+    return p;
+  }
+};
+
+struct DdpgWs {
+  float *a_h0, *a_h1, *ta_h0, *ta_h1, *a_pi, *a_next;
+  float *c_h0, *c_h1, *p_h0, *p_h1, *tc_h0, *tc_h1, *cur, *q_pi, *nq, *dcur;
+  float *g_p0, *g_c0, *dz2, *g_a0, *g_a1;
+  size_t floats;
+  DdpgWs(float *base, const trl_mlp_desc *actor, const trl_mlp_desc *critic, size_t B) {
+    Carve c{base, 0};
+    const size_t A = actor->dims[3];
+    a_h0 = c.take(B * actor->dims[1]); a_h1 = c.take(B * actor->dims[2]);
+    ta_h0 = c.take(B * actor->dims[1]); ta_h1 = c.take(B * actor->dims[2]);
+    a_pi = c.take(B * A); a_next = c.take(B * A);
+    c_h0 = c.take(B * critic->dims[1]); c_h1 = c.take(B * critic->dims[2]);
+    p_h0 = c.take(B * critic->dims[1]); p_h1 = c.take(B * critic->dims[2]);
+    tc_h0 = c.take(B * critic->dims[1]); tc_h1 = c.take(B * critic->dims[2]);
+    cur = c.take(B); q_pi = c.take(B); nq = c.take(B); dcur = c.take(B);
+    g_p0 = c.take(B * critic->dims[1]); g_c0 = c.take(B * critic->dims[1]);
+    dz2 = c.take(B * A);
+    g_a0 = c.take(B * actor->dims[1]); g_a1 = c.take(B * actor->dims[2]);
+    floats = c.off;
+  }
+};
+
+struct DqnWs {
+  float *h0[3], *h1[3], *q[3], *dq, *g0, *g1;
+  size_t floats;
+  DqnWs(float *base, const trl_mlp_desc *net, size_t B) {
+    Carve c{base, 0};
+    for (int j = 0; j < 3; ++j) {
+      h0[j] = c.take(B * net->dims[1]);
+      h1[j] = c.take(B * net->dims[2]);
+      q[j] = c.take(B * net->dims[3]);
+    }
+    dq = c.take(B * net->dims[3]);
+    g0 = c.take(B * net->dims[1]);
+    g1 = c.take(B * net->dims[2]);
+    floats = c.off;
+  }
+};
+
+}  // namespace
+
+extern "C" int64_t trl_ddpg_learn_workspace_bytes(const trl_mlp_desc *actor, const trl_mlp_desc *critic, int64_t B) {
+  if (!actor || !critic || B <= 0) return 0;
+  return (int64_t)(DdpgWs(nullptr, actor, critic, (size_t)B).floats * sizeof(float));
+}
+
+extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_desc *critic,
+                                    const trl_mlp_desc *target_actor, const trl_mlp_desc *target_critic,
+                                    const float *obs, const float *action, const float *reward, const float *next_obs,
+                                    const float *done, int64_t B64, double gamma, int32_t kind, double huber_delta,
+                                    float *losses_out, const trl_adam_args *actor_opt, const trl_adam_args *critic_opt,
+                                    float *target_actor_flat, float *target_critic_flat, double tau, void *ws,
+                                    void *stream) {
+  const char *fn = "trl_ddpg_learn_fused";
+  TRL_REQUIRE(actor_opt && critic_opt, "%s: both optimizer blocks are required (step == 0: gradients only)", fn);
+  int rc;
+  if ((rc = check_net(fn, "actor", actor, actor_opt)) || (rc = check_net(fn, "critic", critic, critic_opt)) ||
+      (rc = check_net(fn, "target_actor", target_actor, nullptr)) ||
+      (rc = check_net(fn, "target_critic", target_critic, nullptr)))
+    return rc;
+  TRL_REQUIRE(same_shape(actor, target_actor) && same_shape(critic, target_critic),
+              "%s: target networks must have the shapes of the online ones", fn);
+  const int S = actor->dims[0], A = actor->dims[3];
+  TRL_REQUIRE(critic->dims[0] == S + A && critic->dims[3] == 1,
+              "%s: critic must map [obs | action] (%d + %d) to one value", fn, S, A);
+  TRL_REQUIRE(B64 >= 16 && B64 % 16 == 0 && B64 <= MAX_BATCH, "%s: B = %lld must be a multiple of 16 in [16, %d]", fn,
+              (long long)B64, MAX_BATCH);
+  TRL_REQUIRE(obs && action && reward && next_obs && done && losses_out && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(kind == TRL_LOSS_MSE || (kind == TRL_LOSS_HUBER && huber_delta > 0), "%s: bad loss kind", fn);
+  TRL_REQUIRE(aligned16(ws), "%s: workspace must be 16 B aligned", fn);
+  const bool update = actor_opt->step > 0;
+  TRL_REQUIRE(update == (critic_opt->step > 0), "%s: update both networks or neither", fn);
+  TRL_REQUIRE(!update || (target_actor_flat && target_critic_flat), "%s: target flat buffers are required", fn);
+  TRL_REQUIRE(!update || (actor_opt->grad_scale == 1.0 && critic_opt->grad_scale == 1.0),
+              "%s: the in-launch update takes unscaled gradients", fn);
+
+  const int B = (int)B64;
+  hipStream_t st = (hipStream_t)stream;
+  const DdpgWs W((float *)ws, actor, critic, (size_t)B);
+  const int Ha0 = actor->dims[1], Ha1 = actor->dims[2], Hc0 = critic->dims[1], Hc1 = critic->dims[2];
+  const trl_mlp_desc *ac = actor, *ta = target_actor, *cr = critic, *tc = target_critic;
+  const Update Ua = make_update(actor_opt, update ? target_actor_flat : nullptr, tau);
+  const Update Uc = make_update(critic_opt, update ? target_critic_flat : nullptr, tau);
+  auto a_off = [&](const float *p) { return (int64_t)(p - actor_opt->param); };
+  auto c_off = [&](const float *p) { return (int64_t)(p - critic_opt->param); };
+
+  {  // layer 0 of actor(obs), target_actor(next_obs), critic(obs, action)
+    Phase ph;
+    add_fwd(ph, B, obs, S, nullptr, 0, ac->w[0], ac->b[0], Ha0, ACT_RELU, W.a_h0);
+    add_fwd(ph, B, next_obs, S, nullptr, 0, ta->w[0], ta->b[0], Ha0, ACT_RELU, W.ta_h0);
+    add_fwd(ph, B, obs, S, action, A, cr->w[0], cr->b[0], Hc0, ACT_RELU, W.c_h0);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {  // layer 1 of the same three
+    Phase ph;
+    add_fwd(ph, B, W.a_h0, Ha0, nullptr, 0, ac->w[1], ac->b[1], Ha1, ACT_RELU, W.a_h1);
+    add_fwd(ph, B, W.ta_h0, Ha0, nullptr, 0, ta->w[1], ta->b[1], Ha1, ACT_RELU, W.ta_h1);
+    add_fwd(ph, B, W.c_h0, Hc0, nullptr, 0, cr->w[1], cr->b[1], Hc1, ACT_RELU, W.c_h1);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {  // pi(obs), pi'(next_obs) (tanh), Q(obs, action)
+    Phase ph;
+    add_fwd(ph, B, W.a_h1, Ha1, nullptr, 0, ac->w[2], ac->b[2], A, ACT_TANH, W.a_pi);
+    add_fwd(ph, B, W.ta_h1, Ha1, nullptr, 0, ta->w[2], ta->b[2], A, ACT_TANH, W.a_next);
+    add_fwd(ph, B, W.c_h1, Hc1, nullptr, 0, cr->w[2], cr->b[2], 1, ACT_NONE, W.cur);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {  // critic(obs, pi(obs)) and target_critic(next_obs, pi'(next_obs)), three layers
+    Phase ph;
+    add_fwd(ph, B, obs, S, W.a_pi, A, cr->w[0], cr->b[0], Hc0, ACT_RELU, W.p_h0);
+    add_fwd(ph, B, next_obs, S, W.a_next, A, tc->w[0], tc->b[0], Hc0, ACT_RELU, W.tc_h0);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {
+    Phase ph;
+    add_fwd(ph, B, W.p_h0, Hc0, nullptr, 0, cr->w[1], cr->b[1], Hc1, ACT_RELU, W.p_h1);
+    add_fwd(ph, B, W.tc_h0, Hc0, nullptr, 0, tc->w[1], tc->b[1], Hc1, ACT_RELU, W.tc_h1);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {
+    Phase ph;
+    add_fwd(ph, B, W.p_h1, Hc1, nullptr, 0, cr->w[2], cr->b[2], 1, ACT_NONE, W.q_pi);
+    add_fwd(ph, B, W.tc_h1, Hc1, nullptr, 0, tc->w[2], tc->b[2], 1, ACT_NONE, W.nq);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  hipLaunchKernelGGL(k_ddpg_losses, dim3(1), dim3(256), 0, st, W.cur, W.q_pi, W.nq, reward, done, B, (float)gamma,
+                     (int)kind, (float)huber_delta, W.dcur, losses_out);
+  TRL_CHECK_LAUNCH(fn);
+
+  const Grad G_p1 = g_virtual(nullptr, -1.0f / (float)B, 1, cr->w[2], W.p_h1);   // d(-mean Q)/d p_h1
+  const Grad G_c1 = g_virtual(W.dcur, 0.f, 1, cr->w[2], W.c_h1);                 // d critic_loss / d c_h1
+  {  // through critic layer 1, both paths
+    Phase ph;
+    add_dx(ph, B, G_p1, Hc1, cr->w[1], Hc0, 0, Hc0, ACT_RELU, W.p_h0, Hc0, W.g_p0, nullptr);
+    add_dx(ph, B, G_c1, Hc1, cr->w[1], Hc0, 0, Hc0, ACT_RELU, W.c_h0, Hc0, W.g_c0, nullptr);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {  // critic layer 1's gradient (+ update); actor path: through critic layer 0's action columns and the tanh
+    Phase ph;
+    ph.a.u[0] = Uc;
+    add_dw(ph, B, G_c1, Hc1, W.c_h0, Hc0, nullptr, 0, c_off(cr->w[1]), c_off(cr->b[1]), 0);
+    add_dx(ph, B, g_material(W.g_p0, Hc0), Hc0, cr->w[0], S + A, S, A, ACT_TANH, W.a_pi, A, W.dz2, nullptr);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {  // through actor layer 1 (keeping the masked outer product for the next launch); critic layers 0 and 2
+    Phase ph;
+    ph.a.u[0] = Uc;
+    add_dx(ph, B, g_virtual(W.dz2, 0.f, A, ac->w[2], W.a_h1), Ha1, ac->w[1], Ha0, 0, Ha0, ACT_RELU, W.a_h0, Ha0,
+           W.g_a0, W.g_a1);
+    add_dw(ph, B, g_material(W.g_c0, Hc0), Hc0, obs, S, action, A, c_off(cr->w[0]), c_off(cr->b[0]), 0);
+    add_dw(ph, B, g_material(W.dcur, 1), 1, W.c_h1, Hc1, nullptr, 0, c_off(cr->w[2]), c_off(cr->b[2]), 0);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {  // the actor's three layers
+    Phase ph;
+    ph.a.u[0] = Ua;
+    add_dw(ph, B, g_material(W.g_a1, Ha1), Ha1, W.a_h0, Ha0, nullptr, 0, a_off(ac->w[1]), a_off(ac->b[1]), 0);
+    add_dw(ph, B, g_material(W.g_a0, Ha0), Ha0, obs, S, nullptr, 0, a_off(ac->w[0]), a_off(ac->b[0]), 0);
+    add_dw(ph, B, g_material(W.dz2, A), A, W.a_h1, Ha1, nullptr, 0, a_off(ac->w[2]), a_off(ac->b[2]), 0);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  return TRL_OK;
+}
+
+extern "C" int64_t trl_dqn_learn_workspace_bytes(const trl_mlp_desc *q_net, int64_t B) {
+  if (!q_net || B <= 0) return 0;
+  return (int64_t)(DqnWs(nullptr, q_net, (size_t)B).floats * sizeof(float)) + trl_loss_workspace_bytes();
+}
+
+extern "C" int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const float *obs,
+                                   const float *action, const float *reward, const float *next_obs, const float *done,
+                                   int64_t B64, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
+                                   float *loss_out, const trl_adam_args *opt, void *ws, void *stream) {
+  const char *fn = "trl_dqn_learn_fused";
+  TRL_REQUIRE(opt != nullptr, "%s: the optimizer block is required (step == 0: gradients only)", fn);
+  int rc;
+  if ((rc = check_net(fn, "q_net", q_net, opt)) || (rc = check_net(fn, "target_net", target_net, nullptr))) return rc;
+  TRL_REQUIRE(same_shape(q_net, target_net), "%s: the target network must have the online one's shape", fn);
+  TRL_REQUIRE(B64 >= 16 && B64 % 16 == 0 && B64 <= MAX_BATCH, "%s: B = %lld must be a multiple of 16 in [16, %d]", fn,
+              (long long)B64, MAX_BATCH);
+  TRL_REQUIRE(obs && action && reward && next_obs && done && loss_out && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(aligned16(ws), "%s: workspace must be 16 B aligned", fn);
+  TRL_REQUIRE(opt->step == 0 || opt->grad_scale == 1.0, "%s: the in-launch update takes unscaled gradients", fn);
+
+  const int B = (int)B64;
+  hipStream_t st = (hipStream_t)stream;
+  const DqnWs W((float *)ws, q_net, (size_t)B);
+  void *loss_ws = (float *)ws + W.floats;
+  const int S = q_net->dims[0], H0 = q_net->dims[1], H1 = q_net->dims[2], A = q_net->dims[3];
+  const Update U = make_update(opt, nullptr, 1.0);
+  auto off = [&](const float *p) { return (int64_t)(p - opt->param); };
+  // 0: q_net(obs), 1: target_net(next_obs), 2: q_net(next_obs) (Double-DQN's argmax, dqn_controller.py:68-69)
+  const trl_mlp_desc *nets[3] = {q_net, target_net, q_net};
+  const float *xs[3] = {obs, next_obs, next_obs};
+  const int npass = double_dqn ? 3 : 2;
+  for (int l = 0; l < 3; ++l) {
+    Phase ph;
+    for (int j = 0; j < npass; ++j) {
+      const float *x = l == 0 ? xs[j] : (l == 1 ? W.h0[j] : W.h1[j]);
+      float *y = l == 0 ? W.h0[j] : (l == 1 ? W.h1[j] : W.q[j]);
+      add_fwd(ph, B, x, nets[j]->dims[l], nullptr, 0, nets[j]->w[l], nets[j]->b[l], nets[j]->dims[l + 1],
+              l < 2 ? ACT_RELU : ACT_NONE, y);
+    }
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  if ((rc = trl_td_loss(W.q[0], W.q[1], double_dqn ? W.q[2] : nullptr, action, reward, done, B, A, gamma, kind,
+                        huber_delta, loss_out, W.dq, loss_ws, stream)))
+    return rc;
+  {
+    Phase ph;
+    add_dx(ph, B, g_virtual(W.dq, 0.f, A, q_net->w[2], W.h1[0]), H1, q_net->w[1], H0, 0, H0, ACT_RELU, W.h0[0], H0,
+           W.g0, W.g1);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  {
+    Phase ph;
+    ph.a.u[0] = U;
+    add_dw(ph, B, g_material(W.g1, H1), H1, W.h0[0], H0, nullptr, 0, off(q_net->w[1]), off(q_net->b[1]), 0);
+    add_dw(ph, B, g_material(W.g0, H0), H0, obs, S, nullptr, 0, off(q_net->w[0]), off(q_net->b[0]), 0);
+    add_dw(ph, B, g_material(W.dq, A), A, W.h1[0], H1, nullptr, 0, off(q_net->w[2]), off(q_net->b[2]), 0);
+    if ((rc = launch(ph, st, fn))) return rc;
+  }
+  return TRL_OK;
+}

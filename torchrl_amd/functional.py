@@ -604,3 +604,155 @@ class FusedPpoLearn:
           adv.data_ptr(), B, self.A, float(alpha), float(beta), losses.data_ptr(), self.gradp[0], self.gradp[1],
           aref, ws.data_ptr(), _lib.stream_ptr(dev)))
     return losses
+
+
+# ------------------------------------------------------------------------------ fused off-policy learner steps
+def _three_layer(lin, max_width=1024):
+  """Linear modules of a two-hidden-layer ReLU stack the phase kernels (csrc/trl_offpolicy.hip) take."""
+  if len(lin) != 3:
+    return False
+  for i, m in enumerate(lin):
+    if m.bias is None or m.weight.dtype != torch.float32 or not m.weight.is_cuda:
+      return False
+    if m.in_features > max_width or m.out_features > max_width:
+      return False
+    if i < 2 and (m.out_features % 16 or m.out_features < 16):
+      return False
+  return True
+
+
+def _flat_ok(flat, lin):
+  """Every parameter of `lin` is a view into flat.data (optim.FlatParams), 16 B-aligned weights."""
+  lo, hi = flat.data.data_ptr(), flat.data.data_ptr() + 4 * flat.data.numel()
+  for m in lin:
+    for t in (m.weight, m.bias):
+      if not (t.is_contiguous() and lo <= t.data_ptr() and t.data_ptr() + 4 * t.numel() <= hi):
+        return False
+    if m.weight.data_ptr() % 16:
+      return False
+  return True
+
+
+class _FusedOffPolicy:
+  MAX_BATCH = 4096
+
+  def _desc(self, descs, i, lin):
+    _fill_desc(descs[i], [m.weight for m in lin], [m.bias for m in lin])
+
+  def usable(self, obs):
+    B = obs.shape[0]
+    return obs.is_cuda and obs.dim() == 2 and obs.dtype == torch.float32 and B >= 16 and B % 16 == 0 \
+        and B <= self.MAX_BATCH and obs.shape[1] == self.S
+
+
+class FusedDdpgLearn(_FusedOffPolicy):
+  """DDPGController.learn's device work as 11 launches (C ABI trl_ddpg_learn_fused,
+  csrc/trl_offpolicy.hip) for two-hidden-layer actor / critic stacks whose parameters live in
+  optim.FlatParams buffers.  Built once per controller; a call is one foreign call."""
+
+  @staticmethod
+  def supports(actor_lin, critic_lin, target_actor_lin, target_critic_lin):
+    if not all(_three_layer(l) for l in (actor_lin, critic_lin, target_actor_lin, target_critic_lin)):
+      return False
+    S, A = actor_lin[0].in_features, actor_lin[2].out_features
+    return critic_lin[0].in_features == S + A and critic_lin[2].out_features == 1
+
+  def __init__(self, actor_lin, critic_lin, target_actor_lin, target_critic_lin, actor_flat, critic_flat,
+               target_actor_flat, target_critic_flat):
+    import ctypes as C
+    self._C = C
+    self.lins = [list(l) for l in (actor_lin, critic_lin, target_actor_lin, target_critic_lin)]
+    self.flats = (actor_flat, critic_flat, target_actor_flat, target_critic_flat)
+    for lin, flat in zip(self.lins, self.flats):
+      if not _flat_ok(flat, lin):
+        raise ValueError('FusedDdpgLearn needs parameters that are views into their FlatParams buffer')
+    self.S, self.A = actor_lin[0].in_features, actor_lin[2].out_features
+    self.device = actor_lin[0].weight.device
+    self.descs = (_lib.MlpDesc * 4)()
+    for i, lin in enumerate(self.lins):
+      self._desc(self.descs, i, lin)
+    self._key = self._ptr_key()
+
+  def _ptr_key(self):
+    return tuple(l[0].weight.data_ptr() for l in self.lins) + tuple(f.data.data_ptr() for f in self.flats)
+
+  def __call__(self, obs, action, reward, next_obs, done, gamma, tau, actor_optim, critic_optim, update=True,
+               huber_delta=None):
+    """update=True: both Adam steps and both Polyak averages happen inside the launches (the
+    optimizers' step counts advance here); False: the gradients land in the flat .grad buffers
+    only.  Returns the [2] loss tensor (actor, critic)."""
+    C = self._C
+    B = obs.shape[0]
+    obs, action, reward = _f32c(obs, 'obs'), _f32c(action, 'action'), _f32c(reward, 'reward')
+    next_obs, done = _f32c(next_obs, 'next_obs'), _f32c(done, 'done')
+    if action.numel() != B * self.A or reward.numel() != B or done.numel() != B or next_obs.shape != obs.shape:
+      raise ValueError('ddpg_learn_fused: inconsistent shapes')
+    if self._ptr_key() != self._key:
+      raise _lib.TrlError('FusedDdpgLearn: parameters were re-homed after construction')
+    dev = obs.device
+    lib = _lib.lib()
+    d = self.descs
+    ws = _linear_ws(dev, lib.trl_ddpg_learn_workspace_bytes(C.byref(d[0]), C.byref(d[1]), B))
+    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    a_args, c_args = actor_optim.fused_args(update), critic_optim.fused_args(update)
+    kind, delta = (0, 0.0) if huber_delta is None else (1, float(huber_delta))
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_ddpg_learn_fused(
+          C.byref(d[0]), C.byref(d[1]), C.byref(d[2]), C.byref(d[3]), obs.data_ptr(), action.data_ptr(),
+          reward.data_ptr(), next_obs.data_ptr(), done.data_ptr(), B, float(gamma), kind, delta, losses.data_ptr(),
+          C.byref(a_args), C.byref(c_args), self.flats[2].data.data_ptr(), self.flats[3].data.data_ptr(), float(tau),
+          ws.data_ptr(), _lib.stream_ptr(dev)))
+    return losses
+
+
+class FusedDqnLearn(_FusedOffPolicy):
+  """DQNController.learn's device work up to the Adam step as 6 launches (C ABI trl_dqn_learn_fused)
+  for two-hidden-layer Q-networks in optim.FlatParams buffers; the periodic hard sync stays with
+  the caller."""
+
+  @staticmethod
+  def supports(q_lin, target_lin):
+    return _three_layer(q_lin) and _three_layer(target_lin)
+
+  def __init__(self, q_lin, target_lin, q_flat, target_flat):
+    import ctypes as C
+    self._C = C
+    self.lins = [list(q_lin), list(target_lin)]
+    self.flats = (q_flat, target_flat)
+    for lin, flat in zip(self.lins, self.flats):
+      if not _flat_ok(flat, lin):
+        raise ValueError('FusedDqnLearn needs parameters that are views into their FlatParams buffer')
+    self.S, self.A = q_lin[0].in_features, q_lin[2].out_features
+    self.device = q_lin[0].weight.device
+    self.descs = (_lib.MlpDesc * 2)()
+    for i, lin in enumerate(self.lins):
+      self._desc(self.descs, i, lin)
+    self._key = self._ptr_key()
+
+  def _ptr_key(self):
+    return tuple(l[0].weight.data_ptr() for l in self.lins) + tuple(f.data.data_ptr() for f in self.flats)
+
+  def __call__(self, obs, action, reward, next_obs, done, gamma, optim, double_dqn=False, update=True,
+               huber_delta=None):
+    """Returns the [1] td-loss tensor."""
+    C = self._C
+    B = obs.shape[0]
+    obs, action, reward = _f32c(obs, 'obs'), _f32c(action, 'action'), _f32c(reward, 'reward')
+    next_obs, done = _f32c(next_obs, 'next_obs'), _f32c(done, 'done')
+    if action.numel() != B or reward.numel() != B or done.numel() != B or next_obs.shape != obs.shape:
+      raise ValueError('dqn_learn_fused: inconsistent shapes')
+    if self._ptr_key() != self._key:
+      raise _lib.TrlError('FusedDqnLearn: parameters were re-homed after construction')
+    dev = obs.device
+    lib = _lib.lib()
+    d = self.descs
+    ws = _linear_ws(dev, lib.trl_dqn_learn_workspace_bytes(C.byref(d[0]), B))
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    args = optim.fused_args(update)
+    kind, delta = (0, 0.0) if huber_delta is None else (1, float(huber_delta))
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_dqn_learn_fused(
+          C.byref(d[0]), C.byref(d[1]), obs.data_ptr(), action.data_ptr(), reward.data_ptr(), next_obs.data_ptr(),
+          done.data_ptr(), B, float(gamma), 1 if double_dqn else 0, kind, delta, loss.data_ptr(), C.byref(args),
+          ws.data_ptr(), _lib.stream_ptr(dev)))
+    return loss
