@@ -169,9 +169,11 @@ def make_rollout(T, N, obs_size, act_size, dev, seed):
 def bench_ppo(args, rank, world, dev):
   T, N, obs_size, act_size = args.T, args.N, 3, 1
   hidden = tuple(int(h) for h in args.hidden.split(','))
-  # 32 minibatches per epoch (T*N / 32 = 262,144 at the default shape), the usual PPO split of a rollout;
-  # --minibatch overrides (65,536 = 128 minibatches per epoch was the earlier default)
-  B = args.minibatch or max(1, (T * N) // 32)
+  # 8 minibatches per epoch (T*N / 8 = 1,048,576 at the default shape): what PPO on thousands of
+  # parallel envs is usually run with (4-8 minibatches per epoch), and 32 optimizer steps -- hence 32
+  # gradient all-reduces on N > 1 ranks -- per rollout.  --minibatch overrides (262,144 = 32 per epoch and
+  # 65,536 = 128 per epoch were the earlier defaults; DESIGN.md section 5 lists all three)
+  B = args.minibatch or max(1, (T * N) // 8)
   steps = args.steps if args.steps is not None else 5
   warmup = args.warmup if args.warmup is not None else 1
   torch.manual_seed(0)

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Host cost of the bit-exact sampler (trl_randperm_prefix) beside torch.randperm, on this host's CPU."""
+import os
+import sys
 import time
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from torchrl_amd.utils.sampler import randperm_prefix
 
