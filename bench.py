@@ -138,10 +138,10 @@ def kernel_time_us(launch, iters):
 
 
 def pmc_traffic(key):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01d_pmc_traffic.json;
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01e_pmc_traffic.json;
   counters cannot be read from inside this process), or None when that launch was not profiled."""
   try:
-    with open(os.path.join(ROOT, 'profiles', 'r01d_pmc_traffic.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r01e_pmc_traffic.json')) as f:
       return int(json.load(f)[key]['hbm_bytes'])
   except (OSError, KeyError, ValueError):
     return None
@@ -393,7 +393,7 @@ def gather_roofline(dev, iters, rows, B, atari):
   out = ds._alloc_out(B)
   us = kernel_time_us(lambda: ds._gather_index(idx, out), iters)
   algo = B * (2 * row_bytes + 8)
-  name = 'k_gather_wide+k_gather_narrow' if atari else 'k_gather_narrow'
+  name = 'k_gather_wide (one launch: wide chunks + narrow tail)' if atari else 'k_gather_narrow'
   key = {(True, 1024): 'k_gather_wide atari B=1024', (False, 65536): 'k_gather_narrow pendulum B=65536'}.get((atari, B))
   r = roofline(name, algo, us, '(2 x %d B row + 8 B index) x B=%d rows gathered from a %d-row ring (%.1f GB)'
                % (row_bytes, B, rows, rows * ds.row_bytes / 1e9), traffic_key=key)
@@ -457,7 +457,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
   us = kernel_time_us(lambda: ds._gather_index(idx, out), args.kernel_iters)
   if atari:   # frames are stored uint8 and handed to the learner as float32 (exact cast in the gather)
     per_row = (2 * 28224 + 12) + 8 + (2 * 28224 * 4 + 12)
-    roof = roofline('k_gather_wide(u8->f32)+k_gather_narrow', B * per_row, us,
+    roof = roofline('k_gather_wide (u8->f32 cast, narrow tail in the same launch)', B * per_row, us,
                     '(%d B u8 record read + 8 B index + %d B f32 batch written) x B=%d'
                     % (2 * 28224 + 12, 2 * 28224 * 4 + 12, B))
   else:

@@ -13,6 +13,8 @@
 //   k_gather_wide    one block per (row, 8 KiB chunk of a wide column), 16 B per lane,
 //                    or 4 B -> float4 per lane when a u8 column is cast to f32.
 // Both are pure HBM/L2 byte movers: no LDS tiling is needed because nothing is reused.
+#include <stdlib.h>
+
 #include "trl_common.h"
 
 namespace {
@@ -84,15 +86,40 @@ __device__ __forceinline__ int64_t logical_to_record(int64_t i, int64_t head, in
   return p;
 }
 
+// Store dword d (value v) of a record into row `orow` of the dense array of the column that holds it.
+__device__ __forceinline__ void store_col_dword(const Hit &h, int d, uint32_t v, int64_t orow) {
+  const int j = d - h.off_dw;
+  if (h.sdt == TRL_F32) {
+    ((uint32_t *)h.ptr)[orow * (h.w_bytes >> 2) + j] = v;
+  } else if (h.odt == TRL_F32) {  // u8 storage, f32 batch (exact)
+    float *o = (float *)h.ptr + orow * h.w_bytes + 4 * j;
+    const int nb = h.w_bytes - 4 * j;
+    if (nb >= 4 && (h.w_bytes & 3) == 0) {
+      *(float4 *)o = make_float4((float)(v & 255u), (float)((v >> 8) & 255u),
+                                 (float)((v >> 16) & 255u), (float)(v >> 24));
+    } else {
+      for (int b = 0; b < (nb < 4 ? nb : 4); ++b) o[b] = (float)((v >> (8 * b)) & 255u);
+    }
+  } else {  // u8 -> u8
+    uint8_t *o = (uint8_t *)h.ptr + orow * h.w_bytes + 4 * j;
+    const int nb = h.w_bytes - 4 * j;
+    if (nb >= 4 && (h.w_bytes & 3) == 0) {
+      *(uint32_t *)o = v;
+    } else {
+      for (int b = 0; b < (nb < 4 ? nb : 4); ++b) o[b] = (uint8_t)(v >> (8 * b));
+    }
+  }
+}
+
 constexpr int NARROW_ROWS = 64;  // rows per block = one wave-wide index load
 
+// 64 rows of the narrow columns: rows [blk * 64, blk * 64 + 64) of the batch.
 template <bool RANGE>
-__global__ __launch_bounds__(256) void k_gather_narrow(
-    const uint32_t *__restrict__ ring, int64_t capacity, int64_t stride_dw, int64_t head,
-    int64_t count, const int64_t *__restrict__ idx, int64_t start, int64_t B, ColArgs a, int nd,
-    uint32_t magic) {
-  __shared__ int64_t s_rec[NARROW_ROWS];
-  const int64_t row0 = (int64_t)blockIdx.x * NARROW_ROWS;
+__device__ __forceinline__ void narrow_block(int64_t blk, const uint32_t *__restrict__ ring, int64_t capacity,
+                                             int64_t stride_dw, int64_t head, int64_t count,
+                                             const int64_t *__restrict__ idx, int64_t start, int64_t B,
+                                             const ColArgs &a, int nd, uint32_t magic, int64_t *s_rec) {
+  const int64_t row0 = blk * NARROW_ROWS;
   const int nrows = (int)((B - row0) < NARROW_ROWS ? (B - row0) : NARROW_ROWS);
   if (threadIdx.x < NARROW_ROWS) {  // wave 0: one coalesced 64 x 8 B index load
     int64_t p = 0;
@@ -110,30 +137,17 @@ __global__ __launch_bounds__(256) void k_gather_narrow(
     int d = 0;
     const Hit h = find_packed(a, e - r * nd, &d);
     if (h.c < 0) continue;
-    const uint32_t v = ring[s_rec[r] + d];
-    const int j = d - h.off_dw;
-    const int64_t orow = row0 + r;
-    if (h.sdt == TRL_F32) {
-      ((uint32_t *)h.ptr)[orow * (h.w_bytes >> 2) + j] = v;
-    } else if (h.odt == TRL_F32) {  // u8 storage, f32 batch (exact)
-      float *o = (float *)h.ptr + orow * h.w_bytes + 4 * j;
-      const int nb = h.w_bytes - 4 * j;
-      if (nb >= 4 && (h.w_bytes & 3) == 0) {
-        *(float4 *)o = make_float4((float)(v & 255u), (float)((v >> 8) & 255u),
-                                   (float)((v >> 16) & 255u), (float)(v >> 24));
-      } else {
-        for (int b = 0; b < (nb < 4 ? nb : 4); ++b) o[b] = (float)((v >> (8 * b)) & 255u);
-      }
-    } else {  // u8 -> u8
-      uint8_t *o = (uint8_t *)h.ptr + orow * h.w_bytes + 4 * j;
-      const int nb = h.w_bytes - 4 * j;
-      if (nb >= 4 && (h.w_bytes & 3) == 0) {
-        *(uint32_t *)o = v;
-      } else {
-        for (int b = 0; b < (nb < 4 ? nb : 4); ++b) o[b] = (uint8_t)(v >> (8 * b));
-      }
-    }
+    store_col_dword(h, d, ring[s_rec[r] + d], row0 + r);
   }
+}
+
+template <bool RANGE>
+__global__ __launch_bounds__(256) void k_gather_narrow(
+    const uint32_t *__restrict__ ring, int64_t capacity, int64_t stride_dw, int64_t head,
+    int64_t count, const int64_t *__restrict__ idx, int64_t start, int64_t B, ColArgs a, int nd,
+    uint32_t magic) {
+  __shared__ int64_t s_rec[NARROW_ROWS];
+  narrow_block<RANGE>(blockIdx.x, ring, capacity, stride_dw, head, count, idx, start, B, a, nd, magic, s_rec);
 }
 
 // ---- wide columns -------------------------------------------------------------------
@@ -149,59 +163,134 @@ struct WideArgs {
   void *ptr[TRL_MAX_COLS];
 };
 
+// One work item = (row b, chunk ch of a wide column): 8 KiB copied as 2 x 16 B per lane, or 4 KiB of u8
+// cast to 16 KiB of f32 (4 x 4 B -> 4 x float4 per lane).  The grid is persistent (a few workgroups per
+// CU striding over the items) and software-pipelined: the loads of a workgroup's next item are issued
+// before the stores of the current one, and the row index of the next item -- a block-uniform scalar
+// load the data loads depend on -- is fetched an item ahead too.  The column table is read into scalar
+// registers once per workgroup and an item is decoded with selects (no dependent scalar loads).
+// The narrow columns of a record (the 12 B action / reward / done tail of an Atari-shaped transition)
+// ride in the same launch: the first `narrow_blocks` workgroups run the narrow kernel's body, so a batch
+// is ONE launch, not a wide and a narrow one with a kernel boundary between them.
+struct WideCols {
+  int off_b[TRL_MAX_COLS], w[TRL_MAX_COLS], cast[TRL_MAX_COLS], cs[TRL_MAX_COLS + 1];
+  char *ptr[TRL_MAX_COLS];
+};
+
+struct WideItem {
+  const char *src;
+  char *dst;
+  int base, w, cast;
+};
+
 template <bool RANGE>
-__global__ __launch_bounds__(256) void k_gather_wide(
-    const char *__restrict__ ring, int64_t capacity, int64_t stride, int64_t head, int64_t count,
-    const int64_t *__restrict__ idx, int64_t start, int64_t B, WideArgs a) {
-  const uint32_t chunks = (uint32_t)a.chunk_start[a.ncols];
-  const uint32_t b = blockIdx.x / chunks;
-  const uint32_t ch = blockIdx.x - b * chunks;
-  int off_b = 0, w = 0, cast = 0, c0 = 0;
-  char *dst = nullptr;
+__device__ __forceinline__ WideItem wide_item(uint32_t item, uint32_t chunks, const char *__restrict__ ring,
+                                              int64_t capacity, int64_t stride, int64_t head, int64_t count,
+                                              const int64_t *__restrict__ idx, int64_t start, const WideCols &c) {
+  const uint32_t b = item / chunks;
+  const int ch = (int)(item - b * chunks);
+  int off_b = c.off_b[0], w = c.w[0], cast = c.cast[0], c0 = 0;
+  char *dst = c.ptr[0];
 #pragma unroll
-  for (int i = 0; i < TRL_MAX_COLS; ++i) {
-    if (i < a.ncols && (int)ch >= a.chunk_start[i] && (int)ch < a.chunk_start[i + 1]) {
-      off_b = a.off_b[i];
-      w = a.w_bytes[i];
-      cast = a.cast[i];
-      c0 = a.chunk_start[i];
-      dst = (char *)a.ptr[i];
-    }
+  for (int i = 1; i < TRL_MAX_COLS; ++i) {   // unused columns have an empty chunk range
+    const bool hit = ch >= c.cs[i];
+    off_b = hit ? c.off_b[i] : off_b;
+    w = hit ? c.w[i] : w;
+    cast = hit ? c.cast[i] : cast;
+    c0 = hit ? c.cs[i] : c0;
+    dst = hit ? c.ptr[i] : dst;
   }
   const int64_t li = RANGE ? start + (int64_t)b : idx[b];  // block-uniform: a scalar load
   const int64_t rec = logical_to_record(li, head, count, capacity);
-  const char *src = ring + rec * stride + off_b;
-  const int lc = (int)ch - c0;
-  if (!cast) {
-    const int base = lc * WIDE_COPY_CHUNK;
-    char *o = dst + (int64_t)b * w;
-    u32x4 v[2];
-    int pos[2];
+  WideItem it;
+  it.src = ring + rec * stride + off_b;
+  it.w = w;
+  it.cast = cast;
+  const int lc = ch - c0;
+  it.base = lc * (cast ? WIDE_CAST_CHUNK : WIDE_COPY_CHUNK);
+  it.dst = dst + (int64_t)b * w * (cast ? 4 : 1);
+  return it;
+}
+
+__device__ __forceinline__ void wide_load(const WideItem &it, u32x4 (&v)[2]) {
+  if (!it.cast) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      pos[u] = base + (u * 256 + (int)threadIdx.x) * 16;
-      if (pos[u] < w) v[u] = __builtin_nontemporal_load((const u32x4 *)(src + pos[u]));
+      const int pos = it.base + (u * 256 + (int)threadIdx.x) * 16;
+      if (pos < it.w) v[u] = __builtin_nontemporal_load((const u32x4 *)(it.src + pos));
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (pos[u] < w) __builtin_nontemporal_store(v[u], (u32x4 *)(o + pos[u]));
   } else {
-    const int base = lc * WIDE_CAST_CHUNK;
-    float *o = (float *)dst + (int64_t)b * w;
-    uint32_t v[4];
-    int pos[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      pos[u] = base + (u * 256 + (int)threadIdx.x) * 4;
-      if (pos[u] < w) v[u] = __builtin_nontemporal_load((const uint32_t *)(src + pos[u]));
+      const int pos = it.base + (u * 256 + (int)threadIdx.x) * 4;
+      if (pos < it.w) v[0][u] = __builtin_nontemporal_load((const uint32_t *)(it.src + pos));
     }
+  }
+}
+
+__device__ __forceinline__ void wide_store(const WideItem &it, const u32x4 (&v)[2]) {
+  if (!it.cast) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (pos[u] < w) {
-        const f32x4 f = {(float)(v[u] & 255u), (float)((v[u] >> 8) & 255u),
-                         (float)((v[u] >> 16) & 255u), (float)(v[u] >> 24)};
-        __builtin_nontemporal_store(f, (f32x4 *)(o + pos[u]));
+    for (int u = 0; u < 2; ++u) {
+      const int pos = it.base + (u * 256 + (int)threadIdx.x) * 16;
+      if (pos < it.w) __builtin_nontemporal_store(v[u], (u32x4 *)(it.dst + pos));
+    }
+  } else {
+    float *o = (float *)it.dst;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pos = it.base + (u * 256 + (int)threadIdx.x) * 4;
+      if (pos < it.w) {
+        const uint32_t x = v[0][u];
+        const f32x4 f = {(float)(x & 255u), (float)((x >> 8) & 255u), (float)((x >> 16) & 255u), (float)(x >> 24)};
+        __builtin_nontemporal_store(f, (f32x4 *)(o + pos));
       }
+    }
+  }
+}
+
+template <bool RANGE>
+__global__ __launch_bounds__(256) void k_gather_wide(
+    const char *__restrict__ ring, int64_t capacity, int64_t stride, int64_t head, int64_t count,
+    const int64_t *__restrict__ idx, int64_t start, int64_t B, WideArgs a, ColArgs na, int nd, uint32_t magic,
+    uint32_t narrow_blocks) {
+  __shared__ int64_t s_rec[NARROW_ROWS];
+  if (blockIdx.x < narrow_blocks) {
+    narrow_block<RANGE>(blockIdx.x, (const uint32_t *)ring, capacity, stride / 4, head, count, idx, start, B, na, nd,
+                        magic, s_rec);
+    return;
+  }
+  WideCols c;
+#pragma unroll
+  for (int i = 0; i < TRL_MAX_COLS; ++i) {
+    c.off_b[i] = a.off_b[i];
+    c.w[i] = a.w_bytes[i];
+    c.cast[i] = a.cast[i];
+    c.cs[i] = a.chunk_start[i];
+    c.ptr[i] = (char *)a.ptr[i];
+  }
+  const uint32_t chunks = (uint32_t)a.chunk_start[TRL_MAX_COLS];
+  const uint32_t total = (uint32_t)B * chunks;
+  const uint32_t step = gridDim.x - narrow_blocks;
+  uint32_t item = blockIdx.x - narrow_blocks;
+  if (item >= total) return;
+  WideItem cur = wide_item<RANGE>(item, chunks, ring, capacity, stride, head, count, idx, start, c);
+  u32x4 vc[2], vn[2];
+  wide_load(cur, vc);
+  for (;;) {
+    const uint32_t next = item + step;
+    const bool more = next < total && next > item;
+    WideItem nxt = cur;
+    if (more) {
+      nxt = wide_item<RANGE>(next, chunks, ring, capacity, stride, head, count, idx, start, c);
+      wide_load(nxt, vn);
+    }
+    wide_store(cur, vc);
+    if (!more) break;
+    cur = nxt;
+    vc[0] = vn[0];
+    vc[1] = vn[1];
+    item = next;
   }
 }
 
@@ -339,30 +428,41 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
       na.pre_dw[i + 1] = na.pre_dw[i] + (layout->col_bytes[c] + 3) / 4;
     }
   }
+  const int nd = na.ncols > 0 ? na.pre_dw[na.ncols] : 0;
+  uint32_t magic = 0;
+  unsigned narrow_blocks = 0;
   if (na.ncols > 0) {
-    const int nd = na.pre_dw[na.ncols];
     TRL_REQUIRE((int64_t)nd * NARROW_ROWS < (1 << 22), "%s: %d narrow dwords per row is too wide for the narrow kernel",
                 fn, nd);
-    const uint32_t magic = (uint32_t)(((1ull << 32) + nd - 1) / nd);
-    const unsigned grid = (unsigned)trl_cdiv(B, NARROW_ROWS);
+    magic = (uint32_t)(((1ull << 32) + nd - 1) / nd);
+    narrow_blocks = (unsigned)trl_cdiv(B, NARROW_ROWS);
+  }
+  if (na.ncols > 0 && wa.ncols == 0) {
     if (range)
-      hipLaunchKernelGGL(k_gather_narrow<true>, dim3(grid), dim3(256), 0, st, (const uint32_t *)ring,
+      hipLaunchKernelGGL(k_gather_narrow<true>, dim3(narrow_blocks), dim3(256), 0, st, (const uint32_t *)ring,
                          capacity, stride / 4, head, count, idx, start, B, na, nd, magic);
     else
-      hipLaunchKernelGGL(k_gather_narrow<false>, dim3(grid), dim3(256), 0, st, (const uint32_t *)ring,
+      hipLaunchKernelGGL(k_gather_narrow<false>, dim3(narrow_blocks), dim3(256), 0, st, (const uint32_t *)ring,
                          capacity, stride / 4, head, count, idx, start, B, na, nd, magic);
     TRL_CHECK_LAUNCH(fn);
   }
   if (wa.ncols > 0) {
-    const int64_t blocks = B * wa.chunk_start[wa.ncols];
-    TRL_REQUIRE(blocks < (1ll << 31), "%s: %lld blocks exceed the grid limit; split the batch", fn,
-                (long long)blocks);
+    // one launch for the whole batch: the first narrow_blocks workgroups copy the narrow columns
+    for (int i = wa.ncols; i < TRL_MAX_COLS; ++i) wa.chunk_start[i + 1] = wa.chunk_start[wa.ncols];   // empty ranges
+    const int64_t items = B * (int64_t)wa.chunk_start[wa.ncols];
+    TRL_REQUIRE(items < (1ll << 31), "%s: %lld chunks exceed the limit; split the batch", fn, (long long)items);
+    // ~4 items per workgroup (measured best on MI355X: the pipeline needs a few items to pay, more
+    // workgroups than that only shorten it), but never fewer than 1024 workgroups when there is work for them
+    int64_t cap_blocks = trl_cdiv(items, 4) > 1024 ? trl_cdiv(items, 4) : 1024;
+    if (const char *t = getenv("TRL_GATHER_WG_PER_CU"))      // tools/gather_sweep.py
+      if (atoi(t) > 0) cap_blocks = (int64_t)256 * atoi(t);
+    const unsigned grid = (unsigned)(items < cap_blocks ? items : cap_blocks) + narrow_blocks;
     if (range)
-      hipLaunchKernelGGL(k_gather_wide<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const char *)ring,
-                         capacity, stride, head, count, idx, start, B, wa);
+      hipLaunchKernelGGL(k_gather_wide<true>, dim3(grid), dim3(256), 0, st, (const char *)ring,
+                         capacity, stride, head, count, idx, start, B, wa, na, nd, magic, narrow_blocks);
     else
-      hipLaunchKernelGGL(k_gather_wide<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const char *)ring,
-                         capacity, stride, head, count, idx, start, B, wa);
+      hipLaunchKernelGGL(k_gather_wide<false>, dim3(grid), dim3(256), 0, st, (const char *)ring,
+                         capacity, stride, head, count, idx, start, B, wa, na, nd, magic, narrow_blocks);
     TRL_CHECK_LAUNCH(fn);
   }
   return TRL_OK;
