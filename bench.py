@@ -58,6 +58,8 @@ def parse():
                        'device = Philox sampler on the GPU (throughput mode, not index-identical)')
   ap.add_argument('--no-gemm-tuning', action='store_true',
                   help='off-policy loops: keep the BLAS default kernel picks (default: PyTorch TunableOp chooses per shape)')
+  ap.add_argument('--f32-frames', action='store_true',
+                  help='dqn_atari: gather the uint8 frames as float32 (the path before the uint8 first layer)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -415,8 +417,12 @@ def bench_offpolicy(args, rank, world, dev, atari):
   if atari:
     cap = args.capacity or 1_000_000
     B = args.minibatch or 256
+    # frames stay uint8 from the ring to the first layer's operand fetch (csrc/trl_linear_u8.hip); --f32-frames
+    # hands the learner float32 frames instead (the cast fused into the gather), the earlier path
+    fdt = torch.float32 if args.f32_frames else torch.uint8
     ds = TensorTupleDataset(size=cap, device=dev,
-                            storage_dtypes=[torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32])
+                            storage_dtypes=[torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32],
+                            gather_dtypes=[fdt, torch.float32, torch.float32, fdt, torch.float32])
     def cols(k):
       return [torch.randint(0, 256, (k, 28224), device=dev, dtype=torch.uint8, generator=g),
               torch.randint(0, 6, (k, 1), device=dev, generator=g).float(),
@@ -427,8 +433,8 @@ def bench_offpolicy(args, rank, world, dev, atari):
     ctl = DQNController(28224, 6, double_dqn=True, gamma=0.99, lr=1e-3, n_update_interval=10, device=dev,
                         graph=args.use_graph)
     row_bytes, name = 2 * 28224 + 12, 'double_dqn_atari'
-    wl = 'double_dqn: %d-row replay of 84x84x4 u8 frames per GPU (%.0f GB), flat-frame QNet 28224-128-128-6' % (
-        cap, cap * ds.row_bytes / 1e9)
+    wl = 'double_dqn: %d-row replay of 84x84x4 u8 frames per GPU (%.0f GB), flat-frame QNet 28224-128-128-6, %s' % (
+        cap, cap * ds.row_bytes / 1e9, 'float32 frames to the learner' if args.f32_frames else 'uint8 frames to the first layer')
   else:
     cap = args.capacity or 1_000_000
     B = args.minibatch or 128
@@ -455,11 +461,14 @@ def bench_offpolicy(args, rank, world, dev, atari):
   idx = torch.randint(0, cap, (B,), device=dev, generator=g)
   out = ds._alloc_out(B)
   us = kernel_time_us(lambda: ds._gather_index(idx, out), args.kernel_iters)
-  if atari:   # frames are stored uint8 and handed to the learner as float32 (exact cast in the gather)
+  if atari and args.f32_frames:   # frames stored uint8, handed to the learner as float32 (exact cast in the gather)
     per_row = (2 * 28224 + 12) + 8 + (2 * 28224 * 4 + 12)
     roof = roofline('k_gather_wide (u8->f32 cast, narrow tail in the same launch)', B * per_row, us,
                     '(%d B u8 record read + 8 B index + %d B f32 batch written) x B=%d'
                     % (2 * 28224 + 12, 2 * 28224 * 4 + 12, B))
+  elif atari:
+    roof = roofline('k_gather_wide (one launch: wide chunks + narrow tail)', B * (2 * row_bytes + 8), us,
+                    '(2 x %d B + 8 B) x B=%d, frames stay uint8' % (row_bytes, B))
   else:
     roof = roofline('k_gather_narrow', B * (2 * row_bytes + 8), us, '(2 x %d B + 8 B) x B=%d' % (row_bytes, B))
   res = {

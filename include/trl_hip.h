@@ -220,6 +220,19 @@ int64_t trl_linear_bwd_workspace_bytes(int64_t B, int32_t K, int32_t N);
 int trl_linear_bwd(const float *dy, const float *y, const float *x, const float *w, int64_t B, int32_t K,
                    int32_t N, int32_t act, float *dx, float *dw, float *db, void *ws, void *stream);
 
+/* The same layer on uint8 input (frames kept uint8 in the replay ring): y = act(float(x) @ w^T + b),
+ * x [B, K] uint8.  Replaces `QNet.net[0]` of torchrl/contrib/models.py:12-18 as DQNController.learn
+ * calls it on stored frames (dqn_controller.py:64-72), which the reference stores as float32
+ * (torchrl/utils/storage.py:65-67): uint8 -> float32 is exact, so the values are the same and the
+ * batch never exists as float32.  N % 128 == 0, K % 32 == 0; `ws` is a caller-owned device scratch of
+ * trl_linear_u8_fwd_workspace_bytes(B, N, K) bytes (split-K partial tiles, summed in a fixed order).
+ * trl_linear_u8_wgrad: dw[N, K] = g[B, N]^T @ float(x)  (OVERWRITTEN; B % 32 == 0, K % 4 == 0). */
+int64_t trl_linear_u8_fwd_workspace_bytes(int64_t B, int32_t N, int32_t K);
+int trl_linear_u8_fwd(const uint8_t *x, const float *w, const float *b, int64_t B, int32_t K, int32_t N,
+                      int32_t act, float *y, void *ws, void *stream);
+int trl_linear_u8_wgrad(const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
+                        void *stream);
+
 /* A whole MLP (Linear -> ReLU -> ... -> Linear, 1..3 Linear layers, every fan-in / fan-out
  * <= 64, e.g. the "MLP 64x64" of the PPO benchmark) in ONE forward launch and ONE backward
  * launch (+ a small reduce): the activations go from layer to layer through LDS.

@@ -1,0 +1,104 @@
+"""First layer on uint8 frames (csrc/trl_linear_u8.hip) against float64 references of the same
+products, and a QNet / DQNController.learn fed uint8 frames against the same fed float32 frames
+(what the reference stores, storage.py:65-67): the cast is exact, so only the summation order differs."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from torchrl_amd import functional as F
+from torchrl_amd.contrib import models
+from torchrl_amd.contrib.controllers import DQNController
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _case(B, K, N, seed):
+  g = torch.Generator().manual_seed(seed)
+  x = torch.randint(0, 256, (B, K), dtype=torch.uint8, generator=g)
+  w = (torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5
+  b = torch.rand(N, generator=g) * 2 - 1
+  return x, w, b
+
+
+@pytest.mark.parametrize('B,K,N', [(256, 28224, 128), (32, 64, 128), (96, 320, 256), (200, 96, 128), (1, 32, 128)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_forward_matches_float64(B, K, N, relu):
+  x, w, b = _case(B, K, N, 1)
+  ref = x.double() @ w.double().t() + b.double()
+  if relu:
+    ref = ref.clamp_min(0)
+  xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+  with torch.no_grad():
+    got = F._LinearU8.apply(xd, wd, bd, 1 if relu else 0).cpu().double()
+  scale = float(ref.abs().max())
+  np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-6, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize('B,K,N', [(256, 28224, 128), (32, 64, 128), (96, 324, 256), (64, 4, 128)])
+def test_wgrad_matches_float64(B, K, N):
+  x, _, _ = _case(B, K, N, 2)
+  g = torch.randn(B, N, generator=torch.Generator().manual_seed(3)) / B
+  ref = g.double().t() @ x.double()
+  dw = torch.full((N, K), float('nan'), device=DEV)
+  from torchrl_amd import _lib
+  gd, xd = g.to(DEV), x.to(DEV)
+  _lib.check(_lib.lib().trl_linear_u8_wgrad(gd.data_ptr(), xd.data_ptr(), B, K, N, dw.data_ptr(), _lib.stream_ptr(torch.device(DEV))))
+  got = dw.cpu().double()
+  assert torch.isfinite(got).all()          # every element written
+  scale = float(ref.abs().max())
+  np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-6, atol=2e-6 * scale)
+
+
+def test_rejects_unsupported_shapes():
+  from torchrl_amd import _lib
+  x, w, b = _case(32, 48, 128, 4)     # K % 32 != 0
+  assert not F.linear_u8_supported(x.to(DEV), w.to(DEV))
+  assert _lib.lib().trl_linear_u8_fwd_workspace_bytes(32, 128, 48) == 0
+  xd, wd, bd, y = x.to(DEV), w.to(DEV), b.to(DEV), torch.empty(32, 128, device=DEV)
+  rc = _lib.lib().trl_linear_u8_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 32, 48, 128, 0, y.data_ptr(),
+                                    y.data_ptr(), None)
+  assert rc == -1 and b'K % 32' in _lib.lib().trl_last_error()
+
+
+def test_qnet_on_uint8_frames_equals_qnet_on_float_frames():
+  torch.manual_seed(0)
+  net = models.QNet(28224, 6).to(DEV)
+  x = torch.randint(0, 256, (64, 28224), dtype=torch.uint8, device=DEV)
+  q8 = net(x)
+  q8.sum().backward()
+  g8 = [p.grad.clone() for p in net.parameters()]
+  net.zero_grad()
+  qf = net(x.float())
+  qf.sum().backward()
+  gf = [p.grad.clone() for p in net.parameters()]
+  np.testing.assert_allclose(q8.detach().cpu().numpy(), qf.detach().cpu().numpy(), rtol=1e-5, atol=1e-5 * float(qf.abs().max()))
+  for a, b_ in zip(g8, gf):
+    np.testing.assert_allclose(a.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(b_.abs().max()))
+  # a shape the HIP layer does not take is cast and runs on the plain modules
+  small = models.QNet(20, 3).to(DEV)
+  xs = torch.randint(0, 256, (8, 20), dtype=torch.uint8, device=DEV)
+  assert torch.equal(small(xs), small(xs.float()))
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_dqn_learn_on_uint8_frames_matches_float_frames(graph):
+  K, A, B = 28224, 6, 64
+  torch.manual_seed(1)
+  c8 = DQNController(K, A, double_dqn=True, gamma=0.99, lr=1e-3, n_update_interval=2, device=DEV, graph=graph)
+  cf = DQNController(K, A, double_dqn=True, gamma=0.99, lr=1e-3, n_update_interval=2, device=DEV, graph=graph)
+  cf._q.data.copy_(c8._q.data)
+  cf._target.data.copy_(c8._target.data)
+  g = torch.Generator(device=DEV).manual_seed(5)
+  for step in range(3):
+    obs = torch.randint(0, 256, (B, K), dtype=torch.uint8, device=DEV, generator=g)
+    nxt = torch.randint(0, 256, (B, K), dtype=torch.uint8, device=DEV, generator=g)
+    act = torch.randint(0, A, (B, 1), device=DEV, generator=g).float()
+    rew = torch.randn(B, 1, device=DEV, generator=g)
+    done = (torch.rand(B, 1, device=DEV, generator=g) < 0.1).float()
+    l8 = c8.learn(obs, act, rew, nxt, done)['td_loss']
+    lf = cf.learn(obs.float(), act, rew, nxt.float(), done)['td_loss']
+    np.testing.assert_allclose(float(l8), float(lf), rtol=2e-5)
+  np.testing.assert_allclose(c8._q.data.cpu().numpy(), cf._q.data.cpu().numpy(), rtol=1e-3, atol=2e-5)

@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LIB_DIR = os.path.join(PKG, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libtrl_hip.so')
 SOURCES = ['trl_host.cpp', 'trl_replay.hip', 'trl_gae.hip', 'trl_loss.hip', 'trl_mlp.hip', 'trl_learn.hip',
-           'trl_offpolicy.hip']
+           'trl_offpolicy.hip', 'trl_linear_u8.hip']
 HEADERS = [os.path.join(CSRC, 'trl_common.h'), os.path.join(ROOT, 'include', 'trl_hip.h')]
 
 # -ffp-contract=off: the parity bar is the reference's op order, one f32 rounding per op.

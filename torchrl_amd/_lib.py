@@ -75,6 +75,9 @@ PROTOTYPES = {
     'trl_linear_fwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     'trl_linear_bwd_workspace_bytes': (_i64, [_i64, _i32, _i32]),
     'trl_linear_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'trl_linear_u8_fwd_workspace_bytes': (_i64, [_i64, _i32, _i32]),
+    'trl_linear_u8_fwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'trl_linear_u8_wgrad': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     'trl_mlp_fwd': (C.c_int, [C.POINTER(MlpDesc), _vp, _i64, C.POINTER(_vp), _vp]),
     'trl_mlp_bwd_workspace_bytes': (_i64, [C.POINTER(MlpDesc), _i64]),
     'trl_mlp_bwd': (C.c_int, [C.POINTER(MlpDesc), _vp, C.POINTER(_vp), _vp, _i64, _vp, C.POINTER(_vp), _vp, _vp]),

@@ -119,7 +119,24 @@ class _Mlp(nn.Sequential):
         i += 1
     return x
 
+  def _u8_head(self, x):
+    """uint8 input (frames the replay ring keeps uint8; the reference holds the same values as
+    float32, storage.py:65-67): the first Linear(+ReLU) reads them as uint8 where the HIP layer
+    takes the shape (csrc/trl_linear_u8.hip), the rest of the stack follows as usual.  Any other
+    uint8 batch is cast first."""
+    mods = list(self)
+    m = mods[0] if mods else None
+    if type(m) in (nn.Linear, SkinnyLinear) and m.bias is not None and _fused_mlp_enabled() and \
+        _F.linear_u8_supported(x, m.weight):
+      relu = len(mods) > 1 and isinstance(mods[1], nn.ReLU)
+      h = _F.linear_u8(x, m.weight, m.bias, relu=relu)
+      rest = mods[2:] if relu else mods[1:]
+      return _Mlp(*rest)(h) if rest else h
+    return self.forward(x.float())
+
   def forward(self, x):
+    if x.dtype == torch.uint8:
+      return self._u8_head(x)
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= self.FUSED_MIN_BATCH
             and _fused_mlp_enabled()):
       return self._plain(x)

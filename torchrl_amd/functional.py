@@ -330,6 +330,52 @@ def linear_act(x, weight, bias, relu=False):
   return _LinearAct.apply(x, weight, bias, 1 if relu else 0)
 
 
+class _LinearU8(torch.autograd.Function):
+  """act(float(x_u8) @ W^T + b) without materialising float(x) (csrc/trl_linear_u8.hip)."""
+
+  @staticmethod
+  def forward(ctx, x, weight, bias, act):
+    w = _f32c(weight, 'weight')
+    b = _f32c(bias, 'bias')
+    B, K = x.shape
+    N = w.shape[0]
+    lib = _lib.lib()
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    ws = _linear_ws(x.device, lib.trl_linear_u8_fwd_workspace_bytes(B, N, K))
+    with torch.cuda.device(x.device):
+      _lib.check(lib.trl_linear_u8_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), B, K, N, act, y.data_ptr(),
+                                       ws.data_ptr(), _lib.stream_ptr(x.device)))
+    ctx.act = act
+    ctx.save_for_backward(x, y)
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    x, y = ctx.saved_tensors
+    g = torch.ops.aten.threshold_backward(gy, y, 0.0) if ctx.act == 1 else gy.contiguous()
+    B, K = x.shape
+    N = g.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().trl_linear_u8_wgrad(g.data_ptr(), x.data_ptr(), B, K, N, dw.data_ptr(),
+                                                _lib.stream_ptr(x.device)))
+    return None, dw, g.sum(0), None
+
+
+def linear_u8_supported(x, weight):
+  """uint8 device batch [B, K] with B % 32 == 0, K % 32 == 0 and a fan-out that is a multiple of 128."""
+  return (x.is_cuda and x.dtype == torch.uint8 and x.dim() == 2 and x.is_contiguous() and x.shape[0] % 32 == 0
+          and x.shape[0] > 0 and x.shape[1] % 32 == 0 and weight.shape[0] % 128 == 0
+          and weight.dtype == torch.float32 and weight.is_contiguous())
+
+
+def linear_u8(x, weight, bias, relu=False):
+  """act(x.float() @ weight^T + bias) for a uint8 device batch, read as uint8: the first layer of a
+  Q-network on frames the replay ring keeps uint8 (the cast is exact: same values as the reference's
+  float32 frames)."""
+  return _LinearU8.apply(x, weight, bias, 1 if relu else 0)
+
+
 def _fill_desc(d, weights, biases):
   d.depth = len(weights)
   d.dims[0] = weights[0].shape[1]
