@@ -63,8 +63,8 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                  help='HIP-graph replay of learn(); auto = off for ppo / a2c / ddpg (their whole step is a handful of '
-                       'fused launches, eager issue keeps up), on for dqn_atari (BLAS + autograd path)')
+                  help='HIP-graph replay of learn(); auto = off wherever the whole step is a handful of fused launches '
+                       '(ppo, a2c, ddpg, dqn_atari on uint8 frames), on for dqn_atari --f32-frames (BLAS + autograd path)')
   ap.add_argument('--no-graph', action='store_true', help='same as --graph off')
   return ap.parse_args()
 
@@ -480,7 +480,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
                  'parallelism': 'dp%d' % world, 'name': name,
                  'gemm_selection': 'blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)',
                  'learn_step': 'hip-graph replay' if args.use_graph else
-                 ('eager, whole step in %d launches (csrc/trl_offpolicy.hip)' % (6 if atari else 11)
+                 ('eager, whole step in %d launches (csrc/trl_offpolicy.hip)' % ((8 if not args.f32_frames else 6) if atari else 11)
                   if getattr(ctl, '_fused', None) is not None else 'eager')},
       'roofline': roof,
   }
@@ -528,7 +528,8 @@ def main():
   args = parse()
   if args.no_graph:
     args.graph = 'off'
-  args.use_graph = args.graph == 'on' or (args.graph == 'auto' and args.workload == 'dqn_atari')
+  # graph replay only where the step is still BLAS + autograd: float32 frames into the flat-frame QNet
+  args.use_graph = args.graph == 'on' or (args.graph == 'auto' and args.workload == 'dqn_atari' and args.f32_frames)
   rank, local, world = setup_dist(args)
   dev = torch.device('cuda', local)
   if args.workload == 'ppo':

@@ -83,6 +83,12 @@ int trl_gather_rows(const void *ring, int64_t capacity, int64_t stride,
                     const int64_t *idx, int64_t B, void *const *dst, const int32_t *out_dtype,
                     void *stream);
 
+/* Host-drawn indices -> device: dst[i] = src_pinned[i], where src_pinned is PINNED (device-mapped) host
+ * memory that the kernel reads directly.  The `.to(self.device)` of the sampled indices at
+ * examples/dqn.py:40-41 / examples/ddpg.py:40-41, without a DMA-engine copy in the middle of the
+ * learner's stream. */
+int trl_stage_indices(const int64_t *src_pinned, int64_t *dst, int64_t n, void *stream);
+
 /* Same as trl_gather_rows for the contiguous logical range [start, start+B) -- the
  * `buffer[:]` form of examples/a2c.py:41 and examples/ppo.py:50 -- with no index array. */
 int trl_gather_range(const void *ring, int64_t capacity, int64_t stride,
@@ -358,6 +364,17 @@ int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc *target_ne
                         const float *action, const float *reward, const float *next_obs, const float *done,
                         int64_t B, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
                         float *loss_out, const trl_adam_args *opt, void *ws, void *stream);
+
+/* The same step on uint8 frames: obs / next_obs are uint8 [B, dims[0]] as the replay ring stores them
+ * (the reference holds the same values as float32, torchrl/utils/storage.py:65-67).  Layer 0 of all
+ * passes (dqn_controller.py:64-72) is one split-K launch + one reduce launch (trl_linear_u8_fwd's
+ * kernels), its weight gradient one launch with Adam in the epilogue: 8 launches per step.  dims[0] % 32
+ * == 0 (any width up to 2^20), dims[1] % 128 == 0, B a multiple of 32. */
+int64_t trl_dqn_learn_u8_workspace_bytes(const trl_mlp_desc *q_net, int64_t B);
+int trl_dqn_learn_fused_u8(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const uint8_t *obs,
+                           const float *action, const float *reward, const uint8_t *next_obs, const float *done,
+                           int64_t B, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
+                           float *loss_out, const trl_adam_args *opt, void *ws, void *stream);
 
 #ifdef __cplusplus
 }

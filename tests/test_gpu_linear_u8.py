@@ -102,3 +102,40 @@ def test_dqn_learn_on_uint8_frames_matches_float_frames(graph):
     lf = cf.learn(obs.float(), act, rew, nxt.float(), done)['td_loss']
     np.testing.assert_allclose(float(l8), float(lf), rtol=2e-5)
   np.testing.assert_allclose(c8._q.data.cpu().numpy(), cf._q.data.cpu().numpy(), rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize('K,A,hidden,B,double_dqn', [(64, 3, 128, 32, True), (320, 6, 128, 96, False),
+                                                     (28224, 6, 128, 64, True), (96, 2, (256, 64), 64, True)])
+def test_dqn_uint8_chain_matches_oracle(K, A, hidden, B, double_dqn):
+  """trl_dqn_learn_fused_u8 (8 launches, frames read as uint8) against the oracle's torch-CPU
+  restatement of DQNController.learn (dqn_controller.py:61-83) on the same frames as float32."""
+  from oracle import loss_oracle
+  rs = np.random.RandomState(K + B)
+  torch.manual_seed(K + 7 * B)
+  ctl = DQNController(K, A, double_dqn=double_dqn, lr=1e-3, n_update_interval=1000, device=DEV, hidden=hidden)
+  assert ctl._fused is not None and ctl._fused.u8_ok
+  with torch.no_grad():       # frames are 0..255: scale the first layer so activations stay O(1)
+    for net in (ctl.q_net, ctl.target_q_net):
+      net.net[0].weight.mul_(1.0 / 64)
+  ctl._target.data.add_(torch.from_numpy(rs.randn(ctl._target.data.numel()).astype(np.float32)).to(DEV) * 1e-3)
+  ref_q, ref_t = copy.deepcopy(ctl.q_net).cpu(), copy.deepcopy(ctl.target_q_net).cpu()
+  opt = torch.optim.Adam(ref_q.parameters(), lr=1e-3)
+  for step in range(2):
+    obs = torch.from_numpy(rs.randint(0, 256, (B, K)).astype(np.uint8))
+    nxt = torch.from_numpy(rs.randint(0, 256, (B, K)).astype(np.uint8))
+    act = torch.from_numpy(rs.randint(0, A, (B, 1)).astype(np.float32))
+    rew = torch.from_numpy(rs.randn(B, 1).astype(np.float32))
+    done = torch.from_numpy((rs.rand(B, 1) < 0.1).astype(np.float32))
+    exp = loss_oracle.dqn_learn(ref_q, ref_t, opt, obs.float(), act, rew, nxt.float(), done, gamma=0.99,
+                                double_dqn=double_dqn)
+    assert ctl._fused.usable(obs.to(DEV))
+    got = ctl.learn(obs.to(DEV), act.to(DEV), rew.to(DEV), nxt.to(DEV), done.to(DEV))
+    e, v = float(exp['td_loss']), float(got['td_loss'])
+    assert abs(v - e) <= 2e-5 * abs(e) + 1e-7, (step, v, e)
+    for (name, p), q in zip(ctl.q_net.named_parameters(), ref_q.parameters()):
+      gq = q.grad.numpy()
+      np.testing.assert_allclose(p.grad.cpu().numpy(), gq, rtol=1e-3, atol=2e-5 * float(np.abs(gq).max()) + 1e-9,
+                                 err_msg='%s grad, step %d' % (name, step))
+  for (name, p), q in zip(ctl.q_net.named_parameters(), ref_q.parameters()):
+    # Adam's first steps move every weight by ~lr whatever the gradient's size: compare on that scale
+    np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), rtol=0, atol=2e-4, err_msg=name)

@@ -75,6 +75,7 @@ PROTOTYPES = {
     'trl_linear_fwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     'trl_linear_bwd_workspace_bytes': (_i64, [_i64, _i32, _i32]),
     'trl_linear_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'trl_stage_indices': (C.c_int, [_vp, _vp, _i64, _vp]),
     'trl_linear_u8_fwd_workspace_bytes': (_i64, [_i64, _i32, _i32]),
     'trl_linear_u8_fwd': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     'trl_linear_u8_wgrad': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
@@ -97,6 +98,9 @@ PROTOTYPES = {
                                        C.POINTER(AdamArgs), C.POINTER(AdamArgs), _vp, _vp, _f64, _vp, _vp]),
     'trl_dqn_learn_workspace_bytes': (_i64, [C.POINTER(MlpDesc), _i64]),
     'trl_dqn_learn_fused': (C.c_int, [C.POINTER(MlpDesc)] * 2 + [_vp] * 5 + [_i64, _f64, _i32, _i32, _f64, _vp,
+                                      C.POINTER(AdamArgs), _vp, _vp]),
+    'trl_dqn_learn_u8_workspace_bytes': (_i64, [C.POINTER(MlpDesc), _i64]),
+    'trl_dqn_learn_fused_u8': (C.c_int, [C.POINTER(MlpDesc)] * 2 + [_vp] * 5 + [_i64, _f64, _i32, _i32, _f64, _vp,
                                       C.POINTER(AdamArgs), _vp, _vp]),
 }
 

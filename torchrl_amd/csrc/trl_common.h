@@ -111,3 +111,15 @@ __device__ __forceinline__ void trl_adam_elem(float *p, float *g, float *m, floa
   *m = mi;
   *v = vi;
 }
+
+// ---- internal launchers of csrc/trl_linear_u8.hip, used by the DQN step chain (csrc/trl_offpolicy.hip)
+struct TrlU8Update {
+  float *pw, *mw, *vw;   // weight [N, K]: parameter, exp_avg, exp_avg_sq
+  float *pb, *mb, *vb;   // bias [N]
+  TrlAdamScalars s;
+};
+int64_t trl_u8_fwd_ws_floats(int64_t B, int32_t N, int32_t K, int P);
+int trl_u8_fwd_launch(const char *fn, int P, const uint8_t *const *x, const float *const *w, const float *const *b,
+                      float *const *y, int64_t B, int32_t K, int32_t N, int32_t act, float *ws, hipStream_t st);
+int trl_u8_wgrad_launch(const char *fn, const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
+                        float *db, const TrlU8Update *u, hipStream_t st);

@@ -16,6 +16,8 @@
 // Both run on v_mfma_f32_32x32x2_f32 (exact f32 products and accumulation); the MFMA sums over its
 // two k slots, and which k sits in which slot is free as long as A and B agree, so a lane walks 16
 // CONSECUTIVE k of its row (one 16 B load = 16 uint8 of x, 4 x 16 B of W) instead of stride-2 ones.
+#include <string.h>
+
 #include "trl_common.h"
 
 namespace {
@@ -29,11 +31,13 @@ __device__ __forceinline__ float ub(unsigned int w, int j) { return (float)((w >
 constexpr int FWD_MT = 128, FWD_NT = 128;   // workgroup tile (4 waves as 2 x 2 of 64 x 64)
 constexpr int KB = 32;                      // k per block: 16 per lane half
 
+constexpr int MAX_PROBLEMS = 3;   // the three first-layer passes of a Double-DQN step share one launch
+
 struct FwdArgs {
-  const uint8_t *x;
-  const float *w;
-  float *ws;       // [S][Bpad][N] partial tiles
-  int B, N, K, Bpad, bps, kblocks;
+  const uint8_t *x[MAX_PROBLEMS];
+  const float *w[MAX_PROBLEMS];
+  float *ws;       // [P][S][Bpad][N] partial tiles
+  int B, N, K, Bpad, bps, kblocks, S;
 };
 
 struct Operands {
@@ -52,6 +56,9 @@ __device__ __forceinline__ void fwd_load(Operands &o, const uint8_t *const (&xr)
 
 __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
   const int s = blockIdx.x;
+  const int pz = blockIdx.z;
+  const uint8_t *xbase = pz == 0 ? a.x[0] : (pz == 1 ? a.x[1] : a.x[2]);
+  const float *wbase = pz == 0 ? a.w[0] : (pz == 1 ? a.w[1] : a.w[2]);
   const int ntn = a.N / FWD_NT;
   const int mt = blockIdx.y / ntn, nt = blockIdx.y - mt * ntn;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
@@ -62,10 +69,10 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
   for (int i = 0; i < 2; ++i) {
     int row = r0 + 32 * i + lr;
     row = row < a.B ? row : a.B - 1;            // padding rows read a valid row; their results are never used
-    xr[i] = a.x + (size_t)row * a.K + 16 * kh;
+    xr[i] = xbase + (size_t)row * a.K + 16 * kh;
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) wr[t] = a.w + (size_t)(n0 + 32 * t + lr) * a.K + 16 * kh;   // N % 128 == 0: always valid
+  for (int t = 0; t < 2; ++t) wr[t] = wbase + (size_t)(n0 + 32 * t + lr) * a.K + 16 * kh;   // N % 128 == 0: always valid
 
   f16v acc[2][2];
 #pragma unroll
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
     if (more) cur = nxt;
   }
   // accumulator layout: lane l, register r holds (row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31)
-  float *ws = a.ws + (size_t)s * a.Bpad * a.N;
+  float *ws = a.ws + ((size_t)pz * a.S + s) * a.Bpad * a.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -108,27 +115,54 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
       }
 }
 
-// y[b, n] = act(sum_s ws[s][b][n] + bias[n]), s in ascending order
-__global__ __launch_bounds__(256) void k_lin_u8_reduce(const float *__restrict__ ws, const float *__restrict__ bias,
-                                                       float *__restrict__ y, int B, int N, int Bpad, int S, int act) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)B * N) return;
-  const int b = (int)(e / N), n = (int)(e - (int64_t)b * N);
-  const size_t plane = (size_t)Bpad * N;
-  const float *p = ws + (size_t)b * N + n;
-  float acc = 0.f;
-  int s = 0;
-  for (; s + 8 <= S; s += 8) {
-    float v[8];
+// y[b, n] = act(sum_s ws[s][b][n] + bias[n]).  A thread sums one of 8 contiguous slices of the S partial
+// tiles for four consecutive n (16 B loads, all of a slice in flight at once); the 8 slice sums are then
+// added in slice order through LDS, so the result does not depend on timing.
+struct ReduceArgs {
+  const float *ws;
+  const float *bias[MAX_PROBLEMS];
+  float *y[MAX_PROBLEMS];
+  int B, N, Bpad, S, act;
+};
+
+constexpr int RED_SLICES = 8, RED_MAX_PER_SLICE = 32;
+
+__global__ __launch_bounds__(256) void k_lin_u8_reduce(ReduceArgs a) {
+  __shared__ f4v part[RED_SLICES][32];
+  const int pz = blockIdx.y;
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t quad = (int64_t)blockIdx.x * 32 + o;          // quad of outputs: (b, n .. n + 3)
+  const int64_t nquads = (int64_t)a.B * a.N / 4;
+  const bool live = quad < nquads;
+  const int64_t e = live ? quad * 4 : 0;
+  const int b = (int)(e / a.N), n = (int)(e - (int64_t)b * a.N);
+  const size_t plane = (size_t)a.Bpad * a.N;
+  const int per = (a.S + RED_SLICES - 1) / RED_SLICES;
+  const int s0 = sl * per, s1 = min(a.S, s0 + per);
+  const float *p = a.ws + (size_t)pz * a.S * plane + (size_t)b * a.N + n;
+  f4v acc = {0.f, 0.f, 0.f, 0.f};
+  f4v v[RED_MAX_PER_SLICE];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * plane];
+  for (int u = 0; u < RED_MAX_PER_SLICE; ++u)
+    if (s0 + u < s1) v[u] = *(const f4v *)(p + (size_t)(s0 + u) * plane);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+  for (int u = 0; u < RED_MAX_PER_SLICE; ++u)
+    if (s0 + u < s1) acc += v[u];
+  part[sl][o] = acc;
+  __syncthreads();
+  if (sl == 0 && live) {
+    f4v t = part[0][o];
+#pragma unroll
+    for (int g = 1; g < RED_SLICES; ++g) t += part[g][o];
+    const float *bias = pz == 0 ? a.bias[0] : (pz == 1 ? a.bias[1] : a.bias[2]);
+    float *y = pz == 0 ? a.y[0] : (pz == 1 ? a.y[1] : a.y[2]);
+    t += *(const f4v *)(bias + n);
+    if (a.act == 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[c] = fmaxf(t[c], 0.f);
+    }
+    *(f4v *)(y + e) = t;
   }
-  for (; s < S; ++s) acc += p[(size_t)s * plane];
-  acc += bias[n];
-  if (act == 1) acc = fmaxf(acc, 0.f);
-  y[e] = acc;
 }
 
 // dW[n, k] = sum_b g[b, n] * x[b, k].  A workgroup owns 128 consecutive k; wave w owns output rows
@@ -138,7 +172,12 @@ __global__ __launch_bounds__(256) void k_lin_u8_reduce(const float *__restrict__
 struct WgradArgs {
   const float *g;
   const uint8_t *x;
-  float *dw;
+  float *dw;       // [N, K] gradient (always written)
+  float *db;       // [N] column sums of g, or NULL
+  // update != 0: torch.optim.Adam's step on the weight (and bias) right where its gradient is produced
+  float *pw, *mw, *vw, *pb, *mb, *vb;
+  TrlAdamScalars s;
+  int update;
   int B, N, K;
 };
 
@@ -190,7 +229,28 @@ __global__ __launch_bounds__(256) void k_lin_u8_wgrad(WgradArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const f4v v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-      *(f4v *)(a.dw + (size_t)n * a.K + kcol) = v;
+      const size_t off = (size_t)n * a.K + kcol;
+      *(f4v *)(a.dw + off) = v;
+      if (a.update) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) trl_adam_elem(a.pw + off + c, a.dw + off + c, a.mw + off + c, a.vw + off + c, a.s);
+      }
+    }
+  }
+  // bias gradient of this wave's 32 output rows: column sums of g, by the workgroups of the first k block;
+  // the two lane halves take alternate 16-row groups of the batch, added in a fixed order
+  if (a.db != nullptr && blockIdx.x == 0) {
+    float sum = 0.f;
+    for (int bb = 0; bb < nblk; ++bb) {
+      const float *g2 = gp + (size_t)bb * 32 * a.N;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum += g2[(size_t)j * a.N];
+    }
+    const float other = __shfl_xor(sum, 32, 64);
+    if (h == 0) {
+      const int n = n0 + i;
+      a.db[n] = sum + other;
+      if (a.update) trl_adam_elem(a.pb + n, a.db + n, a.mb + n, a.vb + n, a.s);
     }
   }
 }
@@ -199,25 +259,80 @@ struct FwdPlan {
   int mtiles, Bpad, kblocks, bps, S;
 };
 
-bool fwd_plan(int64_t B, int32_t N, int32_t K, FwdPlan *p) {
-  if (B <= 0 || N <= 0 || K <= 0 || N % FWD_NT || K % KB || B > (1 << 20)) return false;
+bool fwd_plan(int64_t B, int32_t N, int32_t K, int P, FwdPlan *p) {
+  if (B <= 0 || N <= 0 || K <= 0 || N % FWD_NT || K % KB || B > (1 << 20) || P < 1 || P > MAX_PROBLEMS) return false;
   p->mtiles = (int)((B + FWD_MT - 1) / FWD_MT);
   p->Bpad = p->mtiles * FWD_MT;
   p->kblocks = K / KB;
-  const int tiles = p->mtiles * (N / FWD_NT);
+  const int tiles = p->mtiles * (N / FWD_NT) * P;
   int target = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU over the whole launch
   if (target < 1) target = 1;
-  p->bps = (p->kblocks + target - 1) / target;
+  int bps = (p->kblocks + target - 1) / target;
+  const int min_bps = (p->kblocks + RED_SLICES * RED_MAX_PER_SLICE - 1) / (RED_SLICES * RED_MAX_PER_SLICE);
+  p->bps = bps > min_bps ? bps : min_bps;              // the reduce launch holds at most 256 partial tiles per output
   p->S = (p->kblocks + p->bps - 1) / p->bps;
   return true;
 }
 
 }  // namespace
 
-extern "C" int64_t trl_linear_u8_fwd_workspace_bytes(int64_t B, int32_t N, int32_t K) {
+// Internal launchers (declared in trl_common.h): P first-layer problems of one shape in two launches, and
+// the weight gradient with an optional in-place Adam step.  Arguments are validated by the callers.
+int64_t trl_u8_fwd_ws_floats(int64_t B, int32_t N, int32_t K, int P) {
   FwdPlan p;
-  if (!fwd_plan(B, N, K, &p)) return 0;
-  return (int64_t)p.S * p.Bpad * N * (int64_t)sizeof(float);
+  if (!fwd_plan(B, N, K, P, &p)) return 0;
+  return (int64_t)P * p.S * p.Bpad * N;
+}
+
+int trl_u8_fwd_launch(const char *fn, int P, const uint8_t *const *x, const float *const *w, const float *const *b,
+                      float *const *y, int64_t B, int32_t K, int32_t N, int32_t act, float *ws, hipStream_t st) {
+  FwdPlan p;
+  TRL_REQUIRE(fwd_plan(B, N, K, P, &p), "%s: uint8 first layer needs B in [1, 2^20], N %% 128 == 0, K %% 32 == 0 "
+              "(B=%lld N=%d K=%d)", fn, (long long)B, N, K);
+  FwdArgs a;
+  ReduceArgs r;
+  for (int i = 0; i < MAX_PROBLEMS; ++i) {
+    const int j = i < P ? i : 0;
+    TRL_REQUIRE(x[j] && w[j] && b[j] && y[j], "%s: null pointer", fn);
+    TRL_REQUIRE(((uintptr_t)x[j] % 16 == 0) && ((uintptr_t)w[j] % 16 == 0) && ((uintptr_t)b[j] % 16 == 0) &&
+                ((uintptr_t)y[j] % 16 == 0), "%s: x, w, b and y must be 16 B aligned", fn);
+    a.x[i] = x[j]; a.w[i] = w[j];
+    r.bias[i] = b[j]; r.y[i] = y[j];
+  }
+  TRL_REQUIRE(ws && (uintptr_t)ws % 16 == 0, "%s: workspace must be 16 B aligned", fn);
+  a.ws = ws;
+  a.B = (int)B; a.N = N; a.K = K; a.Bpad = p.Bpad; a.bps = p.bps; a.kblocks = p.kblocks; a.S = p.S;
+  hipLaunchKernelGGL(k_lin_u8_fwd, dim3(p.S, p.mtiles * (N / FWD_NT), P), dim3(256), 0, st, a);
+  TRL_CHECK_LAUNCH(fn);
+  r.ws = ws; r.B = (int)B; r.N = N; r.Bpad = p.Bpad; r.S = p.S; r.act = act;
+  hipLaunchKernelGGL(k_lin_u8_reduce, dim3((unsigned)trl_cdiv(B * N / 4, 32), P), dim3(256), 0, st, r);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+int trl_u8_wgrad_launch(const char *fn, const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
+                        float *db, const TrlU8Update *u, hipStream_t st) {
+  TRL_REQUIRE(g && x && dw, "%s: null pointer", fn);
+  TRL_REQUIRE(B >= 32 && B % 32 == 0 && B <= (1 << 20) && N > 0 && N % 128 == 0 && K >= 4 && K % 4 == 0,
+              "%s: uint8 weight gradient needs B %% 32 == 0, N %% 128 == 0, K %% 4 == 0 (B=%lld N=%d K=%d)", fn,
+              (long long)B, N, K);
+  TRL_REQUIRE(((uintptr_t)x % 4 == 0) && ((uintptr_t)dw % 16 == 0) && ((uintptr_t)g % 4 == 0),
+              "%s: x must be 4 B aligned, dw 16 B aligned", fn);
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.x = x; a.dw = dw; a.db = db; a.B = (int)B; a.N = N; a.K = K;
+  if (u) {
+    TRL_REQUIRE(db && u->pw && u->mw && u->vw && u->pb && u->mb && u->vb, "%s: the in-launch update needs every buffer", fn);
+    a.update = 1;
+    a.pw = u->pw; a.mw = u->mw; a.vw = u->vw; a.pb = u->pb; a.mb = u->mb; a.vb = u->vb; a.s = u->s;
+  }
+  hipLaunchKernelGGL(k_lin_u8_wgrad, dim3((unsigned)trl_cdiv(K, 128), N / 128), dim3(256), 0, st, a);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+extern "C" int64_t trl_linear_u8_fwd_workspace_bytes(int64_t B, int32_t N, int32_t K) {
+  return trl_u8_fwd_ws_floats(B, N, K, 1) * (int64_t)sizeof(float);
 }
 
 extern "C" int trl_linear_u8_fwd(const uint8_t *x, const float *w, const float *b, int64_t B, int32_t K, int32_t N,
@@ -225,34 +340,10 @@ extern "C" int trl_linear_u8_fwd(const uint8_t *x, const float *w, const float *
   const char *fn = "trl_linear_u8_fwd";
   TRL_REQUIRE(x && w && b && y && ws, "%s: null pointer", fn);
   TRL_REQUIRE(act == 0 || act == 1, "%s: act must be 0 (none) or 1 (relu)", fn);
-  FwdPlan p;
-  TRL_REQUIRE(fwd_plan(B, N, K, &p), "%s: need B in [1, 2^20], N %% 128 == 0, K %% 32 == 0 (B=%lld N=%d K=%d)", fn,
-              (long long)B, N, K);
-  TRL_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)ws % 16 == 0),
-              "%s: x, w and ws must be 16 B aligned", fn);
-  hipStream_t st = (hipStream_t)stream;
-  FwdArgs a;
-  a.x = x; a.w = w; a.ws = (float *)ws;
-  a.B = (int)B; a.N = N; a.K = K; a.Bpad = p.Bpad; a.bps = p.bps; a.kblocks = p.kblocks;
-  hipLaunchKernelGGL(k_lin_u8_fwd, dim3(p.S, p.mtiles * (N / FWD_NT)), dim3(256), 0, st, a);
-  TRL_CHECK_LAUNCH(fn);
-  hipLaunchKernelGGL(k_lin_u8_reduce, dim3((unsigned)trl_cdiv(B * N, 256)), dim3(256), 0, st, (const float *)ws, b, y,
-                     (int)B, N, p.Bpad, p.S, act);
-  TRL_CHECK_LAUNCH(fn);
-  return TRL_OK;
+  return trl_u8_fwd_launch(fn, 1, &x, &w, &b, &y, B, K, N, act, (float *)ws, (hipStream_t)stream);
 }
 
 extern "C" int trl_linear_u8_wgrad(const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
                                    void *stream) {
-  const char *fn = "trl_linear_u8_wgrad";
-  TRL_REQUIRE(g && x && dw, "%s: null pointer", fn);
-  TRL_REQUIRE(B >= 32 && B % 32 == 0 && B <= (1 << 20) && N > 0 && N % 128 == 0 && K >= 4 && K % 4 == 0,
-              "%s: need B %% 32 == 0, N %% 128 == 0, K %% 4 == 0 (B=%lld N=%d K=%d)", fn, (long long)B, N, K);
-  TRL_REQUIRE(((uintptr_t)x % 4 == 0) && ((uintptr_t)dw % 16 == 0) && ((uintptr_t)g % 4 == 0),
-              "%s: x must be 4 B aligned, dw 16 B aligned", fn);
-  WgradArgs a;
-  a.g = g; a.x = x; a.dw = dw; a.B = (int)B; a.N = N; a.K = K;
-  hipLaunchKernelGGL(k_lin_u8_wgrad, dim3((unsigned)trl_cdiv(K, 128), N / 128), dim3(256), 0, (hipStream_t)stream, a);
-  TRL_CHECK_LAUNCH(fn);
-  return TRL_OK;
+  return trl_u8_wgrad_launch("trl_linear_u8_wgrad", g, x, B, K, N, dw, nullptr, nullptr, (hipStream_t)stream);
 }

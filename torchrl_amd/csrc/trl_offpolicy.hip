@@ -396,11 +396,13 @@ Update make_update(const trl_adam_args *o, float *target, double tau) {
 
 constexpr int MAX_WIDTH = 1024, MAX_BATCH = 4096;
 
-int check_net(const char *fn, const char *name, const trl_mlp_desc *n, const trl_adam_args *opt) {
+int check_net(const char *fn, const char *name, const trl_mlp_desc *n, const trl_adam_args *opt, bool u8 = false) {
   TRL_REQUIRE(n != nullptr, "%s: %s is NULL", fn, name);
   TRL_REQUIRE(n->depth == 3, "%s: %s must have two hidden layers (depth 3), got depth %d", fn, name, n->depth);
-  TRL_REQUIRE(n->dims[0] >= 1 && n->dims[0] <= MAX_WIDTH && n->dims[3] >= 1 && n->dims[3] <= MAX_WIDTH,
-              "%s: %s fan-in / fan-out out of range", fn, name);
+  TRL_REQUIRE(n->dims[0] >= 1 && (u8 ? n->dims[0] <= (1 << 20) && n->dims[0] % 32 == 0 : n->dims[0] <= MAX_WIDTH) &&
+              n->dims[3] >= 1 && n->dims[3] <= MAX_WIDTH, "%s: %s fan-in / fan-out out of range", fn, name);
+  TRL_REQUIRE(!u8 || n->dims[1] % 128 == 0, "%s: %s: the uint8 first layer needs a fan-out that is a multiple of 128", fn,
+              name);
   for (int l = 1; l <= 2; ++l)
     TRL_REQUIRE(n->dims[l] >= 16 && n->dims[l] % 16 == 0 && n->dims[l] <= MAX_WIDTH,
                 "%s: %s hidden width %d must be a multiple of 16 in [16, %d]", fn, name, n->dims[l], MAX_WIDTH);
@@ -595,22 +597,30 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
   return TRL_OK;
 }
 
-extern "C" int64_t trl_dqn_learn_workspace_bytes(const trl_mlp_desc *q_net, int64_t B) {
-  if (!q_net || B <= 0) return 0;
-  return (int64_t)(DqnWs(nullptr, q_net, (size_t)B).floats * sizeof(float)) + trl_loss_workspace_bytes();
+namespace {
+
+int64_t dqn_ws_floats(const trl_mlp_desc *q_net, int64_t B, bool u8, int npass) {
+  int64_t f = (int64_t)DqnWs(nullptr, q_net, (size_t)B).floats + (trl_loss_workspace_bytes() + 3) / 4;
+  f = (f + 63) / 64 * 64;
+  if (u8) f += trl_u8_fwd_ws_floats(B, q_net->dims[1], q_net->dims[0], npass);
+  return f;
 }
 
-extern "C" int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const float *obs,
-                                   const float *action, const float *reward, const float *next_obs, const float *done,
-                                   int64_t B64, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
-                                   float *loss_out, const trl_adam_args *opt, void *ws, void *stream) {
-  const char *fn = "trl_dqn_learn_fused";
+// obs / next_obs are float32 [B, S], or (u8) uint8 [B, S]: then layer 0 runs on csrc/trl_linear_u8.hip --
+// all passes in one split-K launch + one reduce launch, its weight gradient with the Adam step in the
+// epilogue -- and the rest of the chain is unchanged (8 launches in all).
+int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const void *obs,
+                   const float *action, const float *reward, const void *next_obs, const float *done, int64_t B64,
+                   double gamma, int32_t double_dqn, int32_t kind, double huber_delta, float *loss_out,
+                   const trl_adam_args *opt, void *ws, void *stream) {
   TRL_REQUIRE(opt != nullptr, "%s: the optimizer block is required (step == 0: gradients only)", fn);
   int rc;
-  if ((rc = check_net(fn, "q_net", q_net, opt)) || (rc = check_net(fn, "target_net", target_net, nullptr))) return rc;
+  if ((rc = check_net(fn, "q_net", q_net, opt, u8)) || (rc = check_net(fn, "target_net", target_net, nullptr, u8)))
+    return rc;
   TRL_REQUIRE(same_shape(q_net, target_net), "%s: the target network must have the online one's shape", fn);
-  TRL_REQUIRE(B64 >= 16 && B64 % 16 == 0 && B64 <= MAX_BATCH, "%s: B = %lld must be a multiple of 16 in [16, %d]", fn,
-              (long long)B64, MAX_BATCH);
+  const int bmul = u8 ? 32 : 16;
+  TRL_REQUIRE(B64 >= bmul && B64 % bmul == 0 && B64 <= MAX_BATCH, "%s: B = %lld must be a multiple of %d in [%d, %d]",
+              fn, (long long)B64, bmul, bmul, MAX_BATCH);
   TRL_REQUIRE(obs && action && reward && next_obs && done && loss_out && ws, "%s: NULL argument", fn);
   TRL_REQUIRE(aligned16(ws), "%s: workspace must be 16 B aligned", fn);
   TRL_REQUIRE(opt->step == 0 || opt->grad_scale == 1.0, "%s: the in-launch update takes unscaled gradients", fn);
@@ -624,12 +634,23 @@ extern "C" int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc
   auto off = [&](const float *p) { return (int64_t)(p - opt->param); };
   // 0: q_net(obs), 1: target_net(next_obs), 2: q_net(next_obs) (Double-DQN's argmax, dqn_controller.py:68-69)
   const trl_mlp_desc *nets[3] = {q_net, target_net, q_net};
-  const float *xs[3] = {obs, next_obs, next_obs};
+  const void *xs[3] = {obs, next_obs, next_obs};
   const int npass = double_dqn ? 3 : 2;
+  float *u8_ws = (float *)ws + (W.floats + (trl_loss_workspace_bytes() + 3) / 4 + 63) / 64 * 64;
   for (int l = 0; l < 3; ++l) {
+    if (l == 0 && u8) {
+      const uint8_t *x8[3];
+      const float *w8[3], *b8[3];
+      float *y8[3];
+      for (int j = 0; j < npass; ++j) {
+        x8[j] = (const uint8_t *)xs[j]; w8[j] = nets[j]->w[0]; b8[j] = nets[j]->b[0]; y8[j] = W.h0[j];
+      }
+      if ((rc = trl_u8_fwd_launch(fn, npass, x8, w8, b8, y8, B, S, H0, ACT_RELU, u8_ws, st))) return rc;
+      continue;
+    }
     Phase ph;
     for (int j = 0; j < npass; ++j) {
-      const float *x = l == 0 ? xs[j] : (l == 1 ? W.h0[j] : W.h1[j]);
+      const float *x = l == 0 ? (const float *)xs[j] : (l == 1 ? W.h0[j] : W.h1[j]);
       float *y = l == 0 ? W.h0[j] : (l == 1 ? W.h1[j] : W.q[j]);
       add_fwd(ph, B, x, nets[j]->dims[l], nullptr, 0, nets[j]->w[l], nets[j]->b[l], nets[j]->dims[l + 1],
               l < 2 ? ACT_RELU : ACT_NONE, y);
@@ -645,13 +666,52 @@ extern "C" int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc
            W.g0, W.g1);
     if ((rc = launch(ph, st, fn))) return rc;
   }
+  if (u8) {   // layer 0 first: it reads nothing the next launch writes
+    TrlU8Update up;
+    const int64_t wo = off(q_net->w[0]), bo = off(q_net->b[0]);
+    up.pw = opt->param + wo; up.mw = opt->exp_avg + wo; up.vw = opt->exp_avg_sq + wo;
+    up.pb = opt->param + bo; up.mb = opt->exp_avg + bo; up.vb = opt->exp_avg_sq + bo;
+    up.s = U.s;
+    if ((rc = trl_u8_wgrad_launch(fn, W.g0, (const uint8_t *)obs, B, S, H0, opt->grad + wo, opt->grad + bo,
+                                  U.mode >= UPD_ADAM ? &up : nullptr, st)))
+      return rc;
+  }
   {
     Phase ph;
     ph.a.u[0] = U;
     add_dw(ph, B, g_material(W.g1, H1), H1, W.h0[0], H0, nullptr, 0, off(q_net->w[1]), off(q_net->b[1]), 0);
-    add_dw(ph, B, g_material(W.g0, H0), H0, obs, S, nullptr, 0, off(q_net->w[0]), off(q_net->b[0]), 0);
+    if (!u8) add_dw(ph, B, g_material(W.g0, H0), H0, (const float *)obs, S, nullptr, 0, off(q_net->w[0]), off(q_net->b[0]), 0);
     add_dw(ph, B, g_material(W.dq, A), A, W.h1[0], H1, nullptr, 0, off(q_net->w[2]), off(q_net->b[2]), 0);
     if ((rc = launch(ph, st, fn))) return rc;
   }
   return TRL_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t trl_dqn_learn_workspace_bytes(const trl_mlp_desc *q_net, int64_t B) {
+  if (!q_net || B <= 0) return 0;
+  return dqn_ws_floats(q_net, B, false, 3) * (int64_t)sizeof(float);
+}
+
+extern "C" int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const float *obs,
+                                   const float *action, const float *reward, const float *next_obs, const float *done,
+                                   int64_t B64, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
+                                   float *loss_out, const trl_adam_args *opt, void *ws, void *stream) {
+  return dqn_learn_impl("trl_dqn_learn_fused", false, q_net, target_net, obs, action, reward, next_obs, done, B64, gamma,
+                        double_dqn, kind, huber_delta, loss_out, opt, ws, stream);
+}
+
+extern "C" int64_t trl_dqn_learn_u8_workspace_bytes(const trl_mlp_desc *q_net, int64_t B) {
+  if (!q_net || B <= 0 || q_net->depth != 3) return 0;
+  return dqn_ws_floats(q_net, B, true, 3) * (int64_t)sizeof(float);
+}
+
+extern "C" int trl_dqn_learn_fused_u8(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const uint8_t *obs,
+                                      const float *action, const float *reward, const uint8_t *next_obs,
+                                      const float *done, int64_t B64, double gamma, int32_t double_dqn, int32_t kind,
+                                      double huber_delta, float *loss_out, const trl_adam_args *opt, void *ws,
+                                      void *stream) {
+  return dqn_learn_impl("trl_dqn_learn_fused_u8", true, q_net, target_net, obs, action, reward, next_obs, done, B64,
+                        gamma, double_dqn, kind, huber_delta, loss_out, opt, ws, stream);
 }

@@ -470,6 +470,28 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
 
 }  // namespace
 
+// Indices drawn on the host reach the device through this copy kernel, which reads the caller's pinned
+// (device-mapped) host buffer directly.  A hipMemcpyAsync of the same 2 KB is a DMA-engine job behind a
+// cross-queue dependency on both sides: measured 175 us per learner step on MI355X in the middle of a
+// stream that is otherwise ~180 us of kernels.
+__global__ __launch_bounds__(256) void k_stage_indices(const int64_t *__restrict__ src, int64_t *__restrict__ dst,
+                                                       int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int trl_stage_indices(const int64_t *src_pinned, int64_t *dst, int64_t n, void *stream) {
+  const char *fn = "trl_stage_indices";
+  TRL_REQUIRE(n >= 0, "%s: n < 0", fn);
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(src_pinned && dst, "%s: null pointer", fn);
+  TRL_REQUIRE(((uintptr_t)src_pinned % 8 == 0) && ((uintptr_t)dst % 8 == 0), "%s: pointers must be 8 B aligned", fn);
+  const int64_t blocks = trl_cdiv(n, 256);
+  hipLaunchKernelGGL(k_stage_indices, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
+                     (hipStream_t)stream, src_pinned, dst, n);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
 extern "C" int trl_gather_rows(const void *ring, int64_t capacity, int64_t stride,
                                const trl_ring_layout *layout, int64_t head, int64_t count,
                                const int64_t *idx, int64_t B, void *const *dst,

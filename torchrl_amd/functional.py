@@ -758,7 +758,27 @@ class FusedDqnLearn(_FusedOffPolicy):
 
   @staticmethod
   def supports(q_lin, target_lin):
-    return _three_layer(q_lin) and _three_layer(target_lin)
+    return all(_three_layer(l) or FusedDqnLearn._u8_shape(l) for l in (q_lin, target_lin))
+
+  @staticmethod
+  def _u8_shape(lin):
+    """Stacks whose first layer the uint8 kernels take: any fan-in that is a multiple of 32, fan-out a
+    multiple of 128 (trl_dqn_learn_fused_u8); the rest as _three_layer."""
+    if len(lin) != 3 or lin[0].in_features % 32 or lin[0].in_features > (1 << 20) or lin[0].out_features % 128:
+      return False
+    class _Narrow:     # the first layer with a fan-in _three_layer accepts; everything else as it is
+      pass
+    m0 = _Narrow()
+    m0.bias, m0.weight, m0.in_features, m0.out_features = lin[0].bias, lin[0].weight, 32, lin[0].out_features
+    return _three_layer([m0, lin[1], lin[2]])
+
+  def usable(self, obs):
+    B = obs.shape[0]
+    if not (obs.is_cuda and obs.dim() == 2 and obs.shape[1] == self.S and obs.is_contiguous()):
+      return False
+    if obs.dtype == torch.uint8:
+      return self.u8_ok and B >= 32 and B % 32 == 0 and B <= self.MAX_BATCH
+    return self.f32_ok and obs.dtype == torch.float32 and B >= 16 and B % 16 == 0 and B <= self.MAX_BATCH
 
   def __init__(self, q_lin, target_lin, q_flat, target_flat):
     import ctypes as C
@@ -769,6 +789,8 @@ class FusedDqnLearn(_FusedOffPolicy):
       if not _flat_ok(flat, lin):
         raise ValueError('FusedDqnLearn needs parameters that are views into their FlatParams buffer')
     self.S, self.A = q_lin[0].in_features, q_lin[2].out_features
+    self.f32_ok = all(_three_layer(l) for l in self.lins)
+    self.u8_ok = all(self._u8_shape(l) for l in self.lins)
     self.device = q_lin[0].weight.device
     self.descs = (_lib.MlpDesc * 2)()
     for i, lin in enumerate(self.lins):
@@ -783,8 +805,13 @@ class FusedDqnLearn(_FusedOffPolicy):
     """Returns the [1] td-loss tensor."""
     C = self._C
     B = obs.shape[0]
-    obs, action, reward = _f32c(obs, 'obs'), _f32c(action, 'action'), _f32c(reward, 'reward')
-    next_obs, done = _f32c(next_obs, 'next_obs'), _f32c(done, 'done')
+    u8 = obs.dtype == torch.uint8
+    if u8:
+      if next_obs.dtype != torch.uint8 or not next_obs.is_cuda or not next_obs.is_contiguous():
+        raise ValueError('dqn_learn_fused: obs and next_obs must both be contiguous uint8 device tensors')
+    else:
+      obs, next_obs = _f32c(obs, 'obs'), _f32c(next_obs, 'next_obs')
+    action, reward, done = _f32c(action, 'action'), _f32c(reward, 'reward'), _f32c(done, 'done')
     if action.numel() != B or reward.numel() != B or done.numel() != B or next_obs.shape != obs.shape:
       raise ValueError('dqn_learn_fused: inconsistent shapes')
     if self._ptr_key() != self._key:
@@ -792,12 +819,13 @@ class FusedDqnLearn(_FusedOffPolicy):
     dev = obs.device
     lib = _lib.lib()
     d = self.descs
-    ws = _linear_ws(dev, lib.trl_dqn_learn_workspace_bytes(C.byref(d[0]), B))
+    ws = _linear_ws(dev, (lib.trl_dqn_learn_u8_workspace_bytes if u8 else lib.trl_dqn_learn_workspace_bytes)(
+        C.byref(d[0]), B))
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     args = optim.fused_args(update)
     kind, delta = (0, 0.0) if huber_delta is None else (1, float(huber_delta))
     with torch.cuda.device(dev):
-      _lib.check(lib.trl_dqn_learn_fused(
+      _lib.check((lib.trl_dqn_learn_fused_u8 if u8 else lib.trl_dqn_learn_fused)(
           C.byref(d[0]), C.byref(d[1]), obs.data_ptr(), action.data_ptr(), reward.data_ptr(), next_obs.data_ptr(),
           done.data_ptr(), B, float(gamma), 1 if double_dqn else 0, kind, delta, loss.data_ptr(), C.byref(args),
           ws.data_ptr(), _lib.stream_ptr(dev)))

@@ -64,6 +64,7 @@ class _Layout:
     align = 16 if wide else 4
     self.stride = (off + align - 1) // align * align
     self.offsets = offs
+    self.has_wide = wide
     self.c = _lib.RingLayout()
     self.c.ncols = len(offs)
     for i, (o, b, d) in enumerate(zip(offs, self.col_bytes, self.storage_dtypes)):
@@ -331,10 +332,14 @@ class TensorTupleDataset(Dataset):
     if self._pin_used[slot]:
       ev.synchronize()            # the gather issued 4 calls ago has long finished
     buf[:n].copy_(index)
-    if n <= self.ZERO_COPY_MAX_ROWS and os.environ.get('TRL_INDEX_ZERO_COPY', '1') != '0':
+    # (narrow records only: there one wave per 64 rows reads the indices once; the wide kernel reads a
+    # row's index in every workgroup that copies one of its chunks, which must come from HBM / L2)
+    if n <= self.ZERO_COPY_MAX_ROWS and not self._layout.has_wide and os.environ.get('TRL_INDEX_ZERO_COPY', '1') != '0':
       idx = buf[:n]               # pinned host memory is mapped into the device's address space
-    else:
-      idx = buf[:n].to(self._device, non_blocking=True)
+    else:             # a copy kernel reading the pinned buffer, not a DMA-engine copy (trl_stage_indices)
+      idx = torch.empty(n, dtype=torch.int64, device=self._device)
+      with torch.cuda.device(self._device):
+        _lib.check(_lib.lib().trl_stage_indices(buf.data_ptr(), idx.data_ptr(), n, _lib.stream_ptr(self._device)))
     outs = self._gather_index(idx)
     ev.record(torch.cuda.current_stream(self._device))
     self._pin_used[slot] = True
