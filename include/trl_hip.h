@@ -368,7 +368,8 @@ int trl_dqn_learn_fused(const trl_mlp_desc *q_net, const trl_mlp_desc *target_ne
 /* The same step on uint8 frames: obs / next_obs are uint8 [B, dims[0]] as the replay ring stores them
  * (the reference holds the same values as float32, torchrl/utils/storage.py:65-67).  Layer 0 of all
  * passes (dqn_controller.py:64-72) is one split-K launch + one reduce launch (trl_linear_u8_fwd's
- * kernels), its weight gradient one launch with Adam in the epilogue: 8 launches per step.  dims[0] % 32
+ * kernels), its weight gradient one launch and its Adam step one streaming launch over the layer's slice of
+ * the flat buffers: 9 launches per step.  dims[0] % 32
  * == 0 (any width up to 2^20), dims[1] % 128 == 0, B a multiple of 32. */
 int64_t trl_dqn_learn_u8_workspace_bytes(const trl_mlp_desc *q_net, int64_t B);
 int trl_dqn_learn_fused_u8(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const uint8_t *obs,

@@ -106,6 +106,7 @@ class TensorTupleDataset(Dataset):
     self._head = 0
     self._count = 0
     self._pin = None
+    self._packed_layout = None
     self._stage = None
     if x is not None:
       self.extend(*x)
@@ -231,12 +232,14 @@ class TensorTupleDataset(Dataset):
       s_.record_stream(torch.cuda.current_stream(self._device))
 
   _STAGE_BYTES = 32 << 20
+  _KERNEL_PUSH_BYTES = 4 << 20
 
   def _push_host(self, tensors, k, tail):
     """Rows that are host data (what store() hands over every env step, examples/dqn.py:27-28):
-    packed on the host straight into the ring's record layout in pinned memory and moved with
-    ONE async H2D copy into the ring (two when the write wraps) -- no per-column copies, no
-    kernel.  Large pushes go in slices of the pinned staging size."""
+    packed on the host straight into the ring's record layout in pinned memory, then ONE launch of
+    the push kernel, which reads the pinned records itself (no per-column copies, no DMA-engine copy
+    in the learner's stream).  Bulk loads (more than _KERNEL_PUSH_BYTES per slice) go by async H2D
+    copies straight into the ring, in slices of the pinned staging size."""
     st = self._layout.stride
     rows_per = max(1, self._STAGE_BYTES // st)
     cols = []
@@ -267,10 +270,24 @@ class TensorTupleDataset(Dataset):
       for a, off, nb in zip(cols, self._layout.offsets, self._layout.col_bytes):
         recn[:, off:off + nb] = a[lo:lo + n].view(np.uint8).reshape(n, nb)
       t0 = (tail + lo) % self._capacity
-      first = min(n, self._capacity - t0)
-      ring2d[t0:t0 + first].copy_(rec[:first], non_blocking=True)
-      if first < n:
-        ring2d[:n - first].copy_(rec[first:], non_blocking=True)
+      if n * st <= self._KERNEL_PUSH_BYTES and os.environ.get('TRL_KERNEL_PUSH', '1') != '0':
+        # the per-env-step case: the push kernel reads the packed records straight out of the pinned
+        # buffer (one launch, wrap included).  An async H2D copy of a few hundred bytes is a DMA-engine
+        # job with a cross-queue dependency on either side: ~175 us of stall in the learner's stream.
+        if self._packed_layout is None:
+          lay = _lib.RingLayout()
+          lay.ncols, lay.col_off[0], lay.col_bytes[0], lay.col_dtype[0] = 1, 0, st, _lib.TRL_U8
+          self._packed_layout = lay
+        srcp = (C.c_void_p * 1)(rec.data_ptr())
+        with torch.cuda.device(self._device):
+          _lib.check(_lib.lib().trl_ring_push(self._ring.data_ptr(), self._capacity, st,
+                                              C.byref(self._packed_layout), t0, srcp, n,
+                                              _lib.stream_ptr(self._device)))
+      else:
+        first = min(n, self._capacity - t0)
+        ring2d[t0:t0 + first].copy_(rec[:first], non_blocking=True)
+        if first < n:
+          ring2d[:n - first].copy_(rec[first:], non_blocking=True)
       ev = torch.cuda.Event()
       ev.record(torch.cuda.current_stream(self._device))
       self._stage_ev[slot] = ev
