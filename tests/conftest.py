@@ -13,6 +13,21 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a HIP device (run on the MI355X box)')
+  _build_if_stale_on_cpu()
+
+
+def _build_if_stale_on_cpu():
+  """A fresh checkout has no libtrl_hip.so (built artefacts are git-ignored).  In the build container
+  (no GPU, hipcc present) compile it before the CPU suite so that the C-ABI tests have something to load;
+  on a GPU box nothing is ever built here: the prebuilt library travels with the tree."""
+  import torch
+  from torchrl_amd import _build
+  if torch.cuda.is_available() or not _build.is_stale():
+    return
+  try:
+    _build.build_library(force=False, verbose=False)
+  except Exception as e:  # noqa: BLE001  (no hipcc: the tests that need the library will say so)
+    sys.stderr.write('conftest: could not build libtrl_hip.so: %s\n' % e)
 
 
 def pytest_collection_modifyitems(config, items):
