@@ -252,7 +252,10 @@ def bench_ppo(args, rank, world, dev):
   roof['copy_ceiling'] = {'GB/s': round(algo / us_copy / 1e3, 1), 'us': round(us_copy, 2),
                           'note': 'torch device copy of the same bytes over the same cold buffer sets, same process'}
   roof['frac_of_copy_ceiling'] = round(us_copy / us, 4)
-  extra = {'gae_steps_per_sec_kernel': round(n / (us * 1e-6), 1),
+  share_learn = ms_learn / max(ms_return + ms_learn, 1e-9)
+  extra = {'step_time_share': {'learn epochs (k_ac_learn + k_learn_reduce: see learn_kernel, MFMA-bound)': round(share_learn, 3),
+                               'compute_return (k_ac_infer x2 + k_gae_pipe: see roofline, HBM-bound)': round(1 - share_learn, 3)},
+           'gae_steps_per_sec_kernel': round(n / (us * 1e-6), 1),
            'gae_steps_per_sec_compute_return': round(n / (ms_return * 1e-3), 1),
            'ms_compute_return': round(ms_return, 3), 'ms_learn_epochs': round(ms_learn, 3)}
   res = {
