@@ -167,6 +167,31 @@ __device__ __forceinline__ float row_sum32(const float *row) {
   return (s0 + s1) + (s2 + s3);
 }
 
+// Layer-0 weight gradient on the VALU for observations of at most 4 features (Pendulum 3, CartPole 4):
+// lane = feature n reads its own gradient row g[n][0..31] (which the bias gradient needs anyway) and
+// the 4 rows of x^T as broadcast 16 B reads, and adds  dw[k] += sum_row g[n][row] x[k][row].  On the
+// MFMA this product is 32 instructions per strip (2,048 cycles of the matrix pipe) for a 64 x 3 result
+// padded to 64 x 32; here it is 128 FMAs.  Returns the row sum (same order as row_sum32).
+__device__ __forceinline__ float row_sum32_dw4(const float *grow, const float *sX, float (&dw)[4]) {
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = ld4(grow + 4 * i);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 x = ld4(sX + k * LDT + 4 * i);
+      a0 = fmaf(v[i].x, x.x, a0); a1 = fmaf(v[i].y, x.y, a1); a2 = fmaf(v[i].z, x.z, a2); a3 = fmaf(v[i].w, x.w, a3);
+    }
+    dw[k] += (a0 + a1) + (a2 + a3);
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s0 += v[i].x; s1 += v[i].y; s2 += v[i].z; s3 += v[i].w; }
+  return (s0 + s1) + (s2 + s3);
+}
+
 // ---- forward pieces, shared by the learner kernel and the inference kernel
 // layer 0: h1^T = relu(W0 x^T + b0); x^T from the strip's LDS tile, k walked in natural order
 template <int LDW0>
@@ -296,7 +321,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   __shared__ __align__(16) float sWL[NO * 64];
   __shared__ __align__(16) float sB[2 * 64 + 4];     // b0, b1 (padded with zeros), bL
   __shared__ __align__(16) float sT[4 * WTP];
-  static_assert(WTP >= 64 * 32 * KB0 && (D == 2 || WTP >= 64 * 64) && 4 * WTP >= 4 * 8 * 64 + 64,
+  static_assert(WTP >= 64 * 32 * KB0 && (D == 2 || WTP >= 64 * 64) && 4 * WTP >= 4 * 12 * 64 + 64,
                 "the end-of-kernel reduction re-uses the per-wave scratch");
 
   const int net = blockIdx.y;
@@ -321,6 +346,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   f32x16 accW0[2][KB0];
   f32x16 accW1[2][2];
   float vdb0 = 0.f, vdb1 = 0.f;     // bias gradients of feature `lane`: row sums of the g tiles
+  // fan-in <= 4: dW0[lane][k] accumulates per lane on the VALU (row_sum32_dw4) instead of in accW0
+  const bool w0v = KB0 == 1 && XP && a.dims[0] <= 4;
+  float dw0v[4] = {0.f, 0.f, 0.f, 0.f};
   f32x16 dWL[NO][2];
   float dbL[NO];
 #pragma unroll
@@ -635,7 +663,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     put_tile(sG, g, half, r32);
     wave_lds_fence();
     PH(9);
-    {
+    if (w0v) {
+      vdb0 += row_sum32_dw4(sG + lane * LDT, sX, dw0v);
+    } else {
       const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
       float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), xv[KB0];
 #pragma unroll
@@ -662,8 +692,8 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) xv[kb] = nx[kb];
       }
+      vdb0 += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
     }
-    vdb0 += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
     wave_lds_fence();     // the next strip overwrites sX / sG
     PH(3);
   }
@@ -723,7 +753,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   };
   {
     auto acc0 = [&](int nb, int kb) -> f32x16 & { return accW0[nb][kb < KB0 ? kb : 0]; };
-    flush_tile(acc0, KB0, H1, K0, a.poff[0]);
+    if (!w0v) flush_tile(acc0, KB0, H1, K0, a.poff[0]);     // (workgroup-uniform)
   }
   if (D == 3) {
     auto acc1 = [&](int nb, int kb) -> f32x16 & { return accW1[nb][kb]; };
@@ -731,21 +761,28 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   }
   __syncthreads();
   // ---- per-feature vectors [wave][slot][64] and scalars [wave][16], summed in wave order
-  float *vsum = sT, *scal = sT + 4 * 8 * 64;
-  vsum[(wave * 8 + 0) * 64 + lane] = vec_db0;
-  vsum[(wave * 8 + 1) * 64 + lane] = vec_db1;
+  constexpr int VS = 12;     // slots per wave: db0, db1, NO last-layer rows, 4 dW0 columns (w0v)
+  static_assert(2 + NO + 4 <= VS, "vector slots");
+  float *vsum = sT, *scal = sT + 4 * VS * 64;
+  vsum[(wave * VS + 0) * 64 + lane] = vec_db0;
+  vsum[(wave * VS + 1) * 64 + lane] = vec_db1;
 #pragma unroll
-  for (int n = 0; n < NO; ++n) vsum[(wave * 8 + 2 + n) * 64 + lane] = vec_wl[n];
+  for (int n = 0; n < NO; ++n) vsum[(wave * VS + 2 + n) * 64 + lane] = vec_wl[n];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) vsum[(wave * VS + 2 + NO + k) * 64 + lane] = dw0v[k];
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
   }
   __syncthreads();
-  for (int sl = tid >> 6; sl < 2 + NO; sl += 4) {
+  for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += 4) {
     const int f = tid & 63;
-    const float v = ((vsum[(0 * 8 + sl) * 64 + f] + vsum[(1 * 8 + sl) * 64 + f]) + vsum[(2 * 8 + sl) * 64 + f]) +
-                    vsum[(3 * 8 + sl) * 64 + f];
-    if (sl == 0) {
+    const float v = ((vsum[(0 * VS + sl) * 64 + f] + vsum[(1 * VS + sl) * 64 + f]) + vsum[(2 * VS + sl) * 64 + f]) +
+                    vsum[(3 * VS + sl) * 64 + f];
+    if (sl >= 2 + NO) {
+      const int k = sl - 2 - NO;
+      if (f < H1 && k < K0) part[a.poff[0] + f * K0 + k] = v;
+    } else if (sl == 0) {
       if (f < H1) part[a.poff[0] + H1 * K0 + f] = v;
     } else if (sl == 1) {
       if (D == 3 && f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
