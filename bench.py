@@ -140,10 +140,10 @@ def kernel_time_us(launch, iters):
 
 
 def pmc_traffic(key):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01e_pmc_traffic.json;
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01f_pmc_traffic.json;
   counters cannot be read from inside this process), or None when that launch was not profiled."""
   try:
-    with open(os.path.join(ROOT, 'profiles', 'r01e_pmc_traffic.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r01f_pmc_traffic.json')) as f:
       return int(json.load(f)[key]['hbm_bytes'])
   except (OSError, KeyError, ValueError):
     return None

@@ -31,6 +31,10 @@ clk, rt = st[:, 0::2], st[:, 1::2]
 for i, name in enumerate(('staging', 'strip loop', 'partials out')):
   dc, dr = clk[:, i + 1] - clk[:, i], rt[:, i + 1] - rt[:, i]
   print('%-13s median %8.0f shader cycles  %6.2f us' % (name, np.median(dc), np.median(dr) / 100.0))
+for net, name in enumerate(('critic', 'actor')):      # rows [net * nwg * 4, (net + 1) * nwg * 4) are that network's waves
+  sl = slice(net * nwg * 4, (net + 1) * nwg * 4)
+  dr = rt[sl, 2] - rt[sl, 1]
+  print('strip loop, %-6s waves: median %7.2f us  max %7.2f us' % (name, np.median(dr) / 100.0, dr.max() / 100.0))
 dc, dr = clk[:, 3] - clk[:, 0], rt[:, 3] - rt[:, 0]
 print('whole wave    median %8.0f shader cycles  %6.2f us; clock %.2f GHz' % (np.median(dc), np.median(dr) / 100.0,
                                                                              np.median(dc / dr) * 0.1))
