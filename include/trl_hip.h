@@ -301,6 +301,12 @@ typedef struct {
   int64_t step;      /* 1-based count of this update */
   double grad_scale; /* 1 = none */
   double clip_value; /* <= 0 = none */
+  /* Graph replay (trl_ddpg_learn_fused, trl_dqn_learn_fused[_u8] only; NULL otherwise): the step count
+   * and hyper-parameters live in this DEVICE struct instead of the fields above.  The chain's first
+   * launch increments dev_state->step and derives the bias corrections on the device (as
+   * trl_adam_step_dev does), the update launches read them from there, so every kernel argument of
+   * the chain is the same from step to step and the chain can be captured once and replayed. */
+  trl_adam_state *dev_state;
 } trl_adam_args;
 
 int64_t trl_ppo_learn_workspace_bytes(const trl_mlp_desc *critic, const trl_mlp_desc *actor, int64_t B);

@@ -40,7 +40,7 @@ class AdamArgs(C.Structure):
   """mirror of trl_adam_args"""
   _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
               ('n', C.c_int64), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
-              ('step', C.c_int64), ('grad_scale', C.c_double), ('clip_value', C.c_double)]
+              ('step', C.c_int64), ('grad_scale', C.c_double), ('clip_value', C.c_double), ('dev_state', C.c_void_p)]
 
 
 class TrlError(RuntimeError):

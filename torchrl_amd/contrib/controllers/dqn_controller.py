@@ -57,9 +57,9 @@ class DQNController(Controller):
     self._run = LearnRunner(self._learn_body, [self.q_net_optim], lambda: [], self.device, graph)
 
     # the step up to Adam as 6 launches (csrc/trl_offpolicy.hip) for two-hidden-layer Q-networks up
-    # to 1024 wide / fan-in, eager mode; TRL_FUSED_LEARN=0 keeps the autograd path
+    # to 1024 wide / fan-in (any fan-in for uint8 frames), eager or graph-replayed; TRL_FUSED_LEARN=0 keeps the autograd path
     self._fused = None
-    if self.device.type == 'cuda' and not graph and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+    if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
       lins = [[m for m in net.net if isinstance(m, torch.nn.Linear)] for net in (self.q_net, self.target_q_net)]
       if F.FusedDqnLearn.supports(*lins):
         self._fused = F.FusedDqnLearn(*lins, self._q, self._target)

@@ -123,3 +123,8 @@ int trl_u8_fwd_launch(const char *fn, int P, const uint8_t *const *x, const floa
                       float *const *y, int64_t B, int32_t K, int32_t N, int32_t act, float *ws, hipStream_t st);
 int trl_u8_wgrad_launch(const char *fn, const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
                         float *db, const TrlU8Update *u, hipStream_t st);
+
+// ---- device-resident Adam state (csrc/trl_loss.hip), for chains that are captured into a HIP graph
+int trl_adam_prep_launch(const char *fn, trl_adam_state *state, hipStream_t st);     // ++step, derive the scalars
+int trl_adam_dev_launch(const char *fn, float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                        const trl_adam_state *state, hipStream_t st);                // update with the derived scalars

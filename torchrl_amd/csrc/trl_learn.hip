@@ -1129,6 +1129,7 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   R.losses = losses_out; R.dlog_std = dlog_std; R.B = B; R.A = A; R.kind = kind;
   R.alpha = P.alpha; R.beta = P.beta; R.dls_ent = (float)(-beta / (double)A);
   if (adam) {
+    TRL_REQUIRE(adam->dev_state == nullptr, "%s: the in-launch update keeps its step count on the host (dev_state must be NULL)", fn);
     TRL_REQUIRE(adam->param && adam->grad && adam->exp_avg && adam->exp_avg_sq && adam->n > 0 && adam->step >= 1,
                 "%s: incomplete adam arguments", fn);
     const float *lo = adam->grad, *hi = adam->grad + adam->n;

@@ -503,6 +503,22 @@ extern "C" int trl_adam_step(float *param, float *grad, float *exp_avg, float *e
 
 static_assert(sizeof(AdamScalars) == 32, "AdamScalars must fill trl_adam_state::derived");
 
+int trl_adam_prep_launch(const char *fn, trl_adam_state *state, hipStream_t st) {
+  TRL_REQUIRE(state && (uintptr_t)state % 8 == 0, "%s: the device Adam state must be a non-null 8 B-aligned pointer", fn);
+  hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(64), 0, st, state);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+int trl_adam_dev_launch(const char *fn, float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                        const trl_adam_state *state, hipStream_t st) {
+  TRL_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && n >= 0, "%s: bad Adam arguments", fn);
+  if (n == 0) return TRL_OK;
+  hipLaunchKernelGGL(k_adam_dev, dim3(ew_grid(n)), dim3(NT), 0, st, param, grad, exp_avg, exp_avg_sq, n, state);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
 extern "C" int trl_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                                  trl_adam_state *state, void *stream) {
   const char *fn = "trl_adam_step_dev";

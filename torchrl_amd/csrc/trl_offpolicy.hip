@@ -78,6 +78,7 @@ struct Tile {
 
 struct Update {
   float *param, *grad, *m, *v, *target;
+  const TrlAdamScalars *dev;   // graph replay: the scalars live in the device Adam state, `s` is unused
   TrlAdamScalars s;
   float tau, omt;
   int mode;
@@ -149,7 +150,8 @@ __device__ __forceinline__ f4v mma_range(int kb, int ke, int q, LA load_a, LB lo
 __device__ __forceinline__ void apply_update(const Update &U, int64_t off, float g) {
   U.grad[off] = g;
   if (U.mode >= UPD_ADAM) {
-    trl_adam_elem(U.param + off, U.grad + off, U.m + off, U.v + off, U.s);
+    const TrlAdamScalars sc = U.dev ? *U.dev : U.s;
+    trl_adam_elem(U.param + off, U.grad + off, U.m + off, U.v + off, sc);
     if (U.mode == UPD_ADAM_POLYAK)
       U.target[off] = __fadd_rn(__fmul_rn(U.tau, U.param[off]), __fmul_rn(U.omt, U.target[off]));
   }
@@ -385,7 +387,12 @@ Update make_update(const trl_adam_args *o, float *target, double tau) {
   memset(&U, 0, sizeof(U));
   U.param = o->param; U.grad = o->grad; U.m = o->exp_avg; U.v = o->exp_avg_sq; U.target = target;
   U.mode = UPD_GRAD;
-  if (o->step > 0) {
+  if (o->dev_state) {
+    U.dev = (const TrlAdamScalars *)o->dev_state->derived;
+    U.mode = target ? UPD_ADAM_POLYAK : UPD_ADAM;
+    U.tau = (float)tau;
+    U.omt = (float)(1.0 - tau);
+  } else if (o->step > 0) {
     U.s = trl_adam_scalars(o->lr, o->beta1, o->beta2, o->eps, o->step, o->grad_scale, o->clip_value);
     U.mode = target ? UPD_ADAM_POLYAK : UPD_ADAM;
     U.tau = (float)tau;
@@ -503,10 +510,12 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
   TRL_REQUIRE(obs && action && reward && next_obs && done && losses_out && ws, "%s: NULL argument", fn);
   TRL_REQUIRE(kind == TRL_LOSS_MSE || (kind == TRL_LOSS_HUBER && huber_delta > 0), "%s: bad loss kind", fn);
   TRL_REQUIRE(aligned16(ws), "%s: workspace must be 16 B aligned", fn);
-  const bool update = actor_opt->step > 0;
-  TRL_REQUIRE(update == (critic_opt->step > 0), "%s: update both networks or neither", fn);
+  const bool update = actor_opt->step > 0 || actor_opt->dev_state != nullptr;
+  TRL_REQUIRE(update == (critic_opt->step > 0 || critic_opt->dev_state != nullptr), "%s: update both networks or neither", fn);
+  TRL_REQUIRE((actor_opt->dev_state != nullptr) == (critic_opt->dev_state != nullptr),
+              "%s: both optimizers keep their state on the device, or neither", fn);
   TRL_REQUIRE(!update || (target_actor_flat && target_critic_flat), "%s: target flat buffers are required", fn);
-  TRL_REQUIRE(!update || (actor_opt->grad_scale == 1.0 && critic_opt->grad_scale == 1.0),
+  TRL_REQUIRE(!update || actor_opt->dev_state || (actor_opt->grad_scale == 1.0 && critic_opt->grad_scale == 1.0),
               "%s: the in-launch update takes unscaled gradients", fn);
 
   const int B = (int)B64;
@@ -519,6 +528,10 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
   auto a_off = [&](const float *p) { return (int64_t)(p - actor_opt->param); };
   auto c_off = [&](const float *p) { return (int64_t)(p - critic_opt->param); };
 
+  if (actor_opt->dev_state) {   // graph replay: advance the device step counts, derive this step's scalars
+    if ((rc = trl_adam_prep_launch(fn, actor_opt->dev_state, st)) || (rc = trl_adam_prep_launch(fn, critic_opt->dev_state, st)))
+      return rc;
+  }
   {  // layer 0 of actor(obs), target_actor(next_obs), critic(obs, action)
     Phase ph;
     add_fwd(ph, B, obs, S, nullptr, 0, ac->w[0], ac->b[0], Ha0, ACT_RELU, W.a_h0);
@@ -623,10 +636,11 @@ int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl
               fn, (long long)B64, bmul, bmul, MAX_BATCH);
   TRL_REQUIRE(obs && action && reward && next_obs && done && loss_out && ws, "%s: NULL argument", fn);
   TRL_REQUIRE(aligned16(ws), "%s: workspace must be 16 B aligned", fn);
-  TRL_REQUIRE(opt->step == 0 || opt->grad_scale == 1.0, "%s: the in-launch update takes unscaled gradients", fn);
+  TRL_REQUIRE(opt->step == 0 || opt->dev_state || opt->grad_scale == 1.0, "%s: the in-launch update takes unscaled gradients", fn);
 
   const int B = (int)B64;
   hipStream_t st = (hipStream_t)stream;
+  if (opt->dev_state && (rc = trl_adam_prep_launch(fn, opt->dev_state, st))) return rc;
   const DqnWs W((float *)ws, q_net, (size_t)B);
   void *loss_ws = (float *)ws + W.floats;
   const int S = q_net->dims[0], H0 = q_net->dims[1], H1 = q_net->dims[2], A = q_net->dims[3];
@@ -677,12 +691,15 @@ int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl
       const int64_t nw = (int64_t)H0 * S;
       const bool joined = bo >= wo + nw && bo - (wo + nw) < 64;   // bias right behind the weight (alignment gap only)
       const int64_t spans[2][2] = {{wo, joined ? bo + H0 - wo : nw}, {bo, joined ? 0 : H0}};
-      for (int i = 0; i < 2; ++i)
-        if (spans[i][1] > 0 &&
-            (rc = trl_adam_step(opt->param + spans[i][0], opt->grad + spans[i][0], opt->exp_avg + spans[i][0],
-                                opt->exp_avg_sq + spans[i][0], spans[i][1], opt->lr, opt->beta1, opt->beta2, opt->eps,
-                                opt->step, opt->grad_scale, opt->clip_value, stream)))
-          return rc;
+      for (int i = 0; i < 2; ++i) {
+        if (spans[i][1] <= 0) continue;
+        float *p = opt->param + spans[i][0], *g = opt->grad + spans[i][0], *m = opt->exp_avg + spans[i][0],
+              *v = opt->exp_avg_sq + spans[i][0];
+        rc = opt->dev_state ? trl_adam_dev_launch(fn, p, g, m, v, spans[i][1], opt->dev_state, st)
+                            : trl_adam_step(p, g, m, v, spans[i][1], opt->lr, opt->beta1, opt->beta2, opt->eps, opt->step,
+                                            opt->grad_scale, opt->clip_value, stream);
+        if (rc) return rc;
+      }
     }
   }
   {

@@ -740,7 +740,7 @@ class FusedDdpgLearn(_FusedOffPolicy):
     d = self.descs
     ws = _linear_ws(dev, lib.trl_ddpg_learn_workspace_bytes(C.byref(d[0]), C.byref(d[1]), B))
     losses = torch.empty(2, dtype=torch.float32, device=dev)
-    a_args, c_args = actor_optim.fused_args(update), critic_optim.fused_args(update)
+    a_args, c_args = actor_optim.fused_args(update, True), critic_optim.fused_args(update, True)
     kind, delta = (0, 0.0) if huber_delta is None else (1, float(huber_delta))
     with torch.cuda.device(dev):
       _lib.check(lib.trl_ddpg_learn_fused(
@@ -822,7 +822,7 @@ class FusedDqnLearn(_FusedOffPolicy):
     ws = _linear_ws(dev, (lib.trl_dqn_learn_u8_workspace_bytes if u8 else lib.trl_dqn_learn_workspace_bytes)(
         C.byref(d[0]), B))
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    args = optim.fused_args(update)
+    args = optim.fused_args(update, True)
     kind, delta = (0, 0.0) if huber_delta is None else (1, float(huber_delta))
     with torch.cuda.device(dev):
       _lib.check((lib.trl_dqn_learn_fused_u8 if u8 else lib.trl_dqn_learn_fused)(

@@ -157,23 +157,28 @@ class FlatAdam:
       F.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
                    self.lr, self.betas, self.eps, self.grad_scale, self.clip_value)
 
-  def fused_args(self, update=True):
+  def fused_args(self, update=True, allow_device_state=False):
     """trl_adam_args for a kernel that applies this update itself (trl_ppo_learn_fused,
     trl_ddpg_learn_fused, trl_dqn_learn_fused): advances the host step count, like step().  Not for
     device_state (graph) mode.  update=False: the block with step = 0, which those kernels read as
     "gradients only" (the caller all-reduces and steps afterwards); the count is not advanced."""
-    if self.device_state and update:
-      raise _lib.TrlError('fused Adam is for the eager step (graph mode keeps its step count on the device)')
-    if update:
+    dev = self.device_state and update
+    if dev and not allow_device_state:
+      raise _lib.TrlError('this fused update is for the eager step (graph mode keeps its step count on the device)')
+    if dev and self._state_dev is None:
+      self._push_state()
+    if update and not dev:
       self.step_count += 1
     a = getattr(self, '_fused_args', None)
     if a is None:
       a = self._fused_args = _lib.AdamArgs()
+    # device_state: the chain advances the DEVICE step count itself (note_step mirrors it on the host)
+    a.dev_state = self._state_dev.data_ptr() if dev else None
     a.param, a.grad = self.flat.data.data_ptr(), self.flat.grad.data_ptr()
     a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
     a.n = self.flat.numel
     a.lr, a.beta1, a.beta2, a.eps = self.lr, self.betas[0], self.betas[1], self.eps
-    a.step, a.grad_scale, a.clip_value = (self.step_count if update else 0), self.grad_scale, self.clip_value
+    a.step, a.grad_scale, a.clip_value = (self.step_count if update and not dev else 0), self.grad_scale, self.clip_value
     return a
 
   def note_step(self):
