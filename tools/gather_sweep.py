@@ -12,11 +12,12 @@ import bench  # noqa: E402
 
 def main():
   dev = torch.device('cuda:0')
-  for wg in (0, 4, 16):
+  for un, wg in ((4, 0), (2, 0), (4, 2), (4, 8), (2, 16)):
+    os.environ['TRL_GATHER_UN'] = str(un)
     os.environ["TRL_GATHER_WG_PER_CU"] = str(wg)   # 0 = the library default
     for B in (1024, 256):
       r = bench.gather_roofline(dev, 50, 200_000, B, atari=True)
-      print('wg_per_cu=%-8d B=%-5d %6.2f us  %6.0f GB/s' % (wg, B, r['us_per_launch'], r['achieved']), flush=True)
+      print('un=%d wg_per_cu=%-8d B=%-5d %6.2f us  %6.0f GB/s' % (un, wg, B, r['us_per_launch'], r['achieved']), flush=True)
   os.environ.pop('TRL_GATHER_WG_PER_CU')
 
 

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_gather_narrow(
 }
 
 // ---- wide columns -------------------------------------------------------------------
-constexpr int WIDE_COPY_CHUNK = 8192;  // bytes of a column one block copies (2 x 16 B per lane)
+constexpr int WIDE_COPY_UNIT = 4096;   // a copy item is UN of these (UN x 16 B per lane), UN = 2 or 4
 constexpr int WIDE_CAST_CHUNK = 4096;  // source bytes one block casts (4 x 4 B per lane -> 4 x float4)
 
 struct WideArgs {
@@ -183,7 +183,7 @@ struct WideItem {
   int base, w, cast;
 };
 
-template <bool RANGE>
+template <bool RANGE, int UN>
 __device__ __forceinline__ WideItem wide_item(uint32_t item, uint32_t chunks, const char *__restrict__ ring,
                                               int64_t capacity, int64_t stride, int64_t head, int64_t count,
                                               const int64_t *__restrict__ idx, int64_t start, const WideCols &c) {
@@ -207,15 +207,16 @@ __device__ __forceinline__ WideItem wide_item(uint32_t item, uint32_t chunks, co
   it.w = w;
   it.cast = cast;
   const int lc = ch - c0;
-  it.base = lc * (cast ? WIDE_CAST_CHUNK : WIDE_COPY_CHUNK);
+  it.base = lc * (cast ? WIDE_CAST_CHUNK : UN * WIDE_COPY_UNIT);
   it.dst = dst + (int64_t)b * w * (cast ? 4 : 1);
   return it;
 }
 
-__device__ __forceinline__ void wide_load(const WideItem &it, u32x4 (&v)[2]) {
+template <int UN>
+__device__ __forceinline__ void wide_load(const WideItem &it, u32x4 (&v)[UN]) {
   if (!it.cast) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int pos = it.base + (u * 256 + (int)threadIdx.x) * 16;
       if (pos < it.w) v[u] = __builtin_nontemporal_load((const u32x4 *)(it.src + pos));
     }
@@ -228,10 +229,11 @@ __device__ __forceinline__ void wide_load(const WideItem &it, u32x4 (&v)[2]) {
   }
 }
 
-__device__ __forceinline__ void wide_store(const WideItem &it, const u32x4 (&v)[2]) {
+template <int UN>
+__device__ __forceinline__ void wide_store(const WideItem &it, const u32x4 (&v)[UN]) {
   if (!it.cast) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int pos = it.base + (u * 256 + (int)threadIdx.x) * 16;
       if (pos < it.w) __builtin_nontemporal_store(v[u], (u32x4 *)(it.dst + pos));
     }
@@ -249,7 +251,7 @@ __device__ __forceinline__ void wide_store(const WideItem &it, const u32x4 (&v)[
   }
 }
 
-template <bool RANGE>
+template <bool RANGE, int UN>
 __global__ __launch_bounds__(256) void k_gather_wide(
     const char *__restrict__ ring, int64_t capacity, int64_t stride, int64_t head, int64_t count,
     const int64_t *__restrict__ idx, int64_t start, int64_t B, WideArgs a, ColArgs na, int nd, uint32_t magic,
@@ -274,22 +276,22 @@ __global__ __launch_bounds__(256) void k_gather_wide(
   const uint32_t step = gridDim.x - narrow_blocks;
   uint32_t item = blockIdx.x - narrow_blocks;
   if (item >= total) return;
-  WideItem cur = wide_item<RANGE>(item, chunks, ring, capacity, stride, head, count, idx, start, c);
-  u32x4 vc[2], vn[2];
-  wide_load(cur, vc);
+  WideItem cur = wide_item<RANGE, UN>(item, chunks, ring, capacity, stride, head, count, idx, start, c);
+  u32x4 vc[UN], vn[UN];
+  wide_load<UN>(cur, vc);
   for (;;) {
     const uint32_t next = item + step;
     const bool more = next < total && next > item;
     WideItem nxt = cur;
     if (more) {
-      nxt = wide_item<RANGE>(next, chunks, ring, capacity, stride, head, count, idx, start, c);
-      wide_load(nxt, vn);
+      nxt = wide_item<RANGE, UN>(next, chunks, ring, capacity, stride, head, count, idx, start, c);
+      wide_load<UN>(nxt, vn);
     }
-    wide_store(cur, vc);
+    wide_store<UN>(cur, vc);
     if (!more) break;
     cur = nxt;
-    vc[0] = vn[0];
-    vc[1] = vn[1];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) vc[u] = vn[u];
     item = next;
   }
 }
@@ -403,6 +405,8 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
 
   ColArgs na{};
   WideArgs wa{};
+  int wide_un = 4;                                          // 16 KiB copy items (2: 8 KiB)
+  if (const char *t = getenv("TRL_GATHER_UN")) wide_un = atoi(t) == 2 ? 2 : 4;   // tools/gather_sweep.py
   for (int c = 0; c < layout->ncols; ++c) {
     TRL_REQUIRE(dst[c] != nullptr, "%s: dst[%d] is null", fn, c);
     const int od = out_dtype[c];
@@ -415,7 +419,7 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
       wa.w_bytes[i] = layout->col_bytes[c];
       wa.cast[i] = cast;
       wa.ptr[i] = dst[c];
-      const int chunk = cast ? WIDE_CAST_CHUNK : WIDE_COPY_CHUNK;
+      const int chunk = cast ? WIDE_CAST_CHUNK : wide_un * WIDE_COPY_UNIT;
       wa.chunk_start[i + 1] = wa.chunk_start[i] + (int)trl_cdiv(layout->col_bytes[c], chunk);
     } else {
       TRL_REQUIRE((uintptr_t)dst[c] % 16 == 0, "%s: dst[%d] must be 16-byte aligned", fn, c);
@@ -451,18 +455,21 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
     for (int i = wa.ncols; i < TRL_MAX_COLS; ++i) wa.chunk_start[i + 1] = wa.chunk_start[wa.ncols];   // empty ranges
     const int64_t items = B * (int64_t)wa.chunk_start[wa.ncols];
     TRL_REQUIRE(items < (1ll << 31), "%s: %lld chunks exceed the limit; split the batch", fn, (long long)items);
-    // ~4 items per workgroup (measured best on MI355X: the pipeline needs a few items to pay, more
-    // workgroups than that only shorten it), but never fewer than 1024 workgroups when there is work for them
-    int64_t cap_blocks = trl_cdiv(items, 4) > 1024 ? trl_cdiv(items, 4) : 1024;
+    // persistent grid of 4 workgroups per CU over 16 KiB items (measured best on MI355X among 1-32 per CU
+    // and 8 / 16 KiB items: tools/gather_sweep.py); a small batch is one item per workgroup
+    int64_t cap_blocks = 1024;
     if (const char *t = getenv("TRL_GATHER_WG_PER_CU"))      // tools/gather_sweep.py
       if (atoi(t) > 0) cap_blocks = (int64_t)256 * atoi(t);
     const unsigned grid = (unsigned)(items < cap_blocks ? items : cap_blocks) + narrow_blocks;
-    if (range)
-      hipLaunchKernelGGL(k_gather_wide<true>, dim3(grid), dim3(256), 0, st, (const char *)ring,
-                         capacity, stride, head, count, idx, start, B, wa, na, nd, magic, narrow_blocks);
-    else
-      hipLaunchKernelGGL(k_gather_wide<false>, dim3(grid), dim3(256), 0, st, (const char *)ring,
-                         capacity, stride, head, count, idx, start, B, wa, na, nd, magic, narrow_blocks);
+#define TRL_WIDE_LAUNCH(R, U)                                                                               \
+  hipLaunchKernelGGL((k_gather_wide<R, U>), dim3(grid), dim3(256), 0, st, (const char *)ring, capacity, stride, \
+                     head, count, idx, start, B, wa, na, nd, magic, narrow_blocks)
+    if (range) {
+      if (wide_un == 4) TRL_WIDE_LAUNCH(true, 4); else TRL_WIDE_LAUNCH(true, 2);
+    } else {
+      if (wide_un == 4) TRL_WIDE_LAUNCH(false, 4); else TRL_WIDE_LAUNCH(false, 2);
+    }
+#undef TRL_WIDE_LAUNCH
     TRL_CHECK_LAUNCH(fn);
   }
   return TRL_OK;
