@@ -16,6 +16,7 @@
 // Both run on v_mfma_f32_32x32x2_f32 (exact f32 products and accumulation); the MFMA sums over its
 // two k slots, and which k sits in which slot is free as long as A and B agree, so a lane walks 16
 // CONSECUTIVE k of its row (one 16 B load = 16 uint8 of x, 4 x 16 B of W) instead of stride-2 ones.
+#include <stdlib.h>
 #include <string.h>
 
 #include "trl_common.h"
@@ -265,7 +266,10 @@ bool fwd_plan(int64_t B, int32_t N, int32_t K, int P, FwdPlan *p) {
   p->Bpad = p->mtiles * FWD_MT;
   p->kblocks = K / KB;
   const int tiles = p->mtiles * (N / FWD_NT) * P;
-  int target = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU over the whole launch
+  int total_wgs = 512;                                 // ~2 workgroups per CU over the whole launch (flat optimum 256-768: tools/u8_fwd_sweep.py)
+  if (const char *t = getenv("TRL_U8_FWD_WGS"))        // tools: sweep of the split count
+    if (atoi(t) > 0) total_wgs = atoi(t);
+  int target = (total_wgs + tiles - 1) / tiles;
   if (target < 1) target = 1;
   int bps = (p->kblocks + target - 1) / target;
   const int min_bps = (p->kblocks + RED_SLICES * RED_MAX_PER_SLICE - 1) / (RED_SLICES * RED_MAX_PER_SLICE);
