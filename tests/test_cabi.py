@@ -88,3 +88,29 @@ def test_generator_argument():
   g2 = torch.Generator().manual_seed(99)
   assert torch.equal(randperm_prefix(1000, 50, generator=g1), torch.randperm(1000, generator=g2)[:50])
   assert torch.equal(torch.rand(3, generator=g1), torch.rand(3, generator=g2))
+
+
+def test_sampler_jump_ahead_equals_direct_skip_and_torch(monkeypatch):
+  """Rings of more than ~2.6 M rows skip their n - 1 - B unused words by polynomial jump-ahead once the
+  same skip length has been seen three times (csrc/trl_host.cpp, namespace jump).  Same indices, same
+  generator state as the block-by-block skip, and as torch.randperm itself."""
+  from torchrl_amd.utils.sampler import Mt19937Sampler, randperm_prefix
+  n, B = 2_700_001, 48
+  jumped, direct = Mt19937Sampler(31), Mt19937Sampler(31)
+  monkeypatch.delenv('TRL_MT_NO_JUMP', raising=False)
+  a = [jumped.randperm_prefix(n, B).numpy().copy() for _ in range(8)]
+  monkeypatch.setenv('TRL_MT_NO_JUMP', '1')
+  b = [direct.randperm_prefix(n, B).numpy().copy() for _ in range(8)]
+  monkeypatch.delenv('TRL_MT_NO_JUMP')
+  for x, y in zip(a, b):
+    np.testing.assert_array_equal(x, y)
+  np.testing.assert_array_equal(jumped._mt, direct._mt)
+  assert (jumped._left.value, jumped._next.value) == (direct._left.value, direct._next.value)
+  torch.manual_seed(11)
+  exp = [torch.randperm(n)[:B].clone() for _ in range(6)]
+  after = torch.randint(0, 2 ** 31, (4,))
+  torch.manual_seed(11)
+  got = [randperm_prefix(n, B) for _ in range(6)]
+  for x, y in zip(exp, got):
+    assert torch.equal(x, y)
+  assert torch.equal(after, torch.randint(0, 2 ** 31, (4,)))

@@ -10,9 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from torchrl_amd.utils.sampler import randperm_prefix
 
-for n in (100_000, 1_000_000, 10_000_000):
-  randperm_prefix(n, 128)
-  k = 30
+for n in (1_000_000, 3_000_000, 10_000_000):
+  for _ in range(8):      # past the point where the jump polynomials of a full ring's two skip lengths exist
+    randperm_prefix(n, 128)
+  k = 40
   t = time.perf_counter()
   for _ in range(k):
     randperm_prefix(n, 128)

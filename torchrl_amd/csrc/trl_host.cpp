@@ -14,6 +14,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
 #include "trl_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -68,6 +72,8 @@ void mt_regen_many(uint32_t *s, int64_t k) {
   if (k == 1) mt_regen(s);
 }
 
+bool jump_regen_many(uint32_t *s, int64_t r);   // O(1) in r for a full ring's steady r (defined below)
+
 struct Mt {
   uint32_t *s;
   int32_t left, next;
@@ -97,11 +103,235 @@ struct Mt {
     // [1, 624] draws taken from the newest state the position is left = 625 - c, next = c
     const int64_t r = (k + MT_N - 1) / MT_N;
     const int64_t c = k - (r - 1) * MT_N;
-    mt_regen_many(s, r);
+    if (!jump_regen_many(s, r)) mt_regen_many(s, r);
     left = (int32_t)(MT_N + 1 - c);
     next = (int32_t)c;
   }
 };
+
+
+// ---- jump-ahead: r regenerations in O(1) ----------------------------------------------------------------
+// A sample from a full ring of n rows skips n - 1 - B words = r = (n - 1 - B) / 624 regenerations, always the
+// same r (or r + 1) once the ring is full; at 37 ns per regeneration that is 0.06 ms at n = 1 M but 0.6 ms at
+// 10 M.  MT19937 is linear over GF(2): with phi = the minimal polynomial of its one-word shift F (degree
+// 19937) and g_J = x^J mod phi, the state J words ahead is g_J(F) applied to the current state, which Horner's
+// rule evaluates with deg(g) <= 19936 single-word steps and one 624-word XOR per set coefficient (~10^4):
+// about 0.15 ms whatever J is (Haramoto, Matsumoto, Nishimura, Panneton, L'Ecuyer, "Efficient jump ahead for
+// F2-linear random number generators", 2008).  phi comes from Berlekamp-Massey on 2 x 19937 output bits, once
+// per process; g_J costs ~40 ms to build, so it is built only for a J seen three times (a full ring), and the
+// direct skip stays in use below JUMP_MIN_BLOCKS and while the ring is filling.
+// The 624-word array holds 31 bits more than the generator's state (the low bits of word 0, which the next
+// regeneration does not read); g_J(F) reproduces F^J on everything else, so the jump covers r - 1 blocks
+// and the last one is a plain regeneration, whose 624 output words depend only on the bits that are right.
+namespace jump {
+constexpr int DEG = 19937;
+constexpr int PW = 312;                       // 64-bit words of a polynomial of degree < 19968
+typedef uint64_t Poly[PW];
+
+inline int bit(const uint64_t *p, int i) { return (int)((p[i >> 6] >> (i & 63)) & 1u); }
+inline void flip(uint64_t *p, int i) { p[i >> 6] ^= 1ull << (i & 63); }
+
+uint64_t g_phi[PW + 1];                       // bits 0 .. 19937
+bool g_phi_ok = false;
+
+// minimal polynomial of the bit sequence b (N bits) by Berlekamp-Massey, bit-packed: returns L, conn[0..L]
+int berlekamp_massey(const uint8_t *b, int N, std::vector<uint64_t> &conn) {
+  const int W = (N + 64) / 64 + 1;
+  std::vector<uint64_t> C(W, 0), Bp(W, 0), T(W, 0), win(W, 0);   // win bit i = b[n - i]
+  C[0] = Bp[0] = 1;
+  int L = 0, m = 1;
+  for (int n = 0; n < N; ++n) {
+    // win <<= 1; win bit 0 = b[n]
+    uint64_t carry = b[n];
+    const int wl = (n >> 6) + 1;
+    for (int i = 0; i < wl && i < W; ++i) {
+      const uint64_t nc = win[i] >> 63;
+      win[i] = (win[i] << 1) | carry;
+      carry = nc;
+    }
+    // d = sum_{i=0..L} C_i b[n-i]
+    uint64_t acc = 0;
+    const int cl = (L >> 6) + 1;
+    for (int i = 0; i < cl; ++i) acc ^= C[i] & win[i];
+    if (__builtin_parityll(acc)) {
+      const bool grow = 2 * L <= n;
+      if (grow) T = C;
+      // C ^= Bp << m
+      const int ws = m >> 6, bs = m & 63;
+      const int bl = (n >> 6) + 2;
+      for (int i = 0; i + ws < W && i < bl; ++i) {
+        C[i + ws] ^= Bp[i] << bs;
+        if (bs && i + ws + 1 < W) C[i + ws + 1] ^= Bp[i] >> (64 - bs);
+      }
+      if (grow) {
+        L = n + 1 - L;
+        Bp = T;
+        m = 1;
+      } else {
+        ++m;
+      }
+    } else {
+      ++m;
+    }
+  }
+  conn = C;
+  return L;
+}
+
+bool build_phi() {
+  // 2 * DEG output bits (bit 0 of the tempered words) of a generator seeded like torch's, seed 5489
+  uint32_t mt[MT_N];
+  int32_t left = 1, next = 0;
+  trl_mt19937_seed(mt, &left, &next, 5489);
+  Mt g{mt, left, next};
+  const int N = 2 * DEG + 64;
+  std::vector<uint8_t> bits(N);
+  for (int i = 0; i < N; ++i) bits[i] = (uint8_t)(g.draw() & 1u);
+  std::vector<uint64_t> conn;
+  const int L = berlekamp_massey(bits.data(), N, conn);
+  if (L != DEG) return false;
+  // sum_{i=0..L} conn_i s[n-i] = 0  ->  characteristic polynomial phi_j = conn_{L-j}
+  memset(g_phi, 0, sizeof(g_phi));
+  for (int j = 0; j <= DEG; ++j)
+    if (bit(conn.data(), DEG - j)) flip(g_phi, j);
+  return bit(g_phi, DEG) == 1 && bit(g_phi, 0) == 1;
+}
+
+// p (degree < 2 * DEG, 2 * PW words) mod phi, result in the low PW words
+void reduce(uint64_t *p) {
+  for (int i = 2 * DEG - 2; i >= DEG; --i) {
+    if (!bit(p, i)) continue;
+    const int sh = i - DEG, ws = sh >> 6, bs = sh & 63;
+    for (int k = 0; k <= PW; ++k) {
+      const uint64_t v = g_phi[k];
+      if (!v) continue;
+      p[k + ws] ^= v << bs;
+      if (bs) p[k + ws + 1] ^= v >> (64 - bs);
+    }
+  }
+}
+
+// g = x^J mod phi
+void pow_x(uint64_t J, uint64_t *g) {
+  std::vector<uint64_t> p(2 * PW + 4, 0), q(2 * PW + 4, 0);
+  p[0] = 1;                                                    // 1
+  int top = 63;
+  while (top > 0 && !((J >> top) & 1)) --top;
+  for (int b = top; b >= 0; --b) {
+    // square: spread the bits
+    std::fill(q.begin(), q.end(), 0);
+    for (int i = 0; i < DEG; ++i)
+      if (bit(p.data(), i)) flip(q.data(), 2 * i);
+    reduce(q.data());
+    for (int k = 0; k < 2 * PW + 4; ++k) p[k] = k < PW ? q[k] : 0;
+    p[PW - 1] &= (1ull << (DEG - 64 * (PW - 1))) - 1;          // keep bits < DEG (the rest was reduced away)
+    if ((J >> b) & 1) {                                        // times x
+      uint64_t carry = 0;
+      for (int k = 0; k < PW; ++k) {
+        const uint64_t nc = p[k] >> 63;
+        p[k] = (p[k] << 1) | carry;
+        carry = nc;
+      }
+      if (bit(p.data(), DEG)) {
+        for (int k = 0; k <= PW && k < 2 * PW + 4; ++k) p[k] ^= g_phi[k];
+      }
+    }
+  }
+  memcpy(g, p.data(), PW * sizeof(uint64_t));
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void xor_state(uint32_t *__restrict__ d, const uint32_t *__restrict__ s) {
+  for (int i = 0; i < MT_N; ++i) d[i] ^= s[i];
+}
+
+// s <- g(F) s for the one-word shift F.  Horner's rule over the coefficients of g from the top, on a window
+// that slides up a linear buffer (one step of F appends one word), taking the coefficients Q at a time: a run
+// of up to Q coefficients that starts and ends with a 1 is one XOR with a precomputed combination
+// T[v] = sum_b v_b F^b s  (sliding-window method of the jump-ahead paper: ~deg / (Q + 1) XORs of 624 words
+// instead of one per set coefficient).
+constexpr int Q = 5;
+
+void apply(const uint64_t *g, uint32_t *s) {
+  int top = DEG - 1;
+  while (top > 0 && !bit(g, top)) --top;
+  static thread_local std::vector<uint32_t> buf, tab;
+  // ext[b .. b + 624) = F^b s for b < Q
+  uint32_t ext[MT_N + Q];
+  memcpy(ext, s, MT_N * sizeof(uint32_t));
+  for (int b = 0; b < Q - 1; ++b) ext[MT_N + b] = ext[MT_M + b] ^ twist(ext[b], ext[b + 1]);
+  tab.assign((size_t)(1 << Q) * MT_N, 0);
+  for (int v = 1; v < (1 << Q); v += 2)
+    for (int b = 0; b < Q; ++b)
+      if ((v >> b) & 1) xor_state(tab.data() + (size_t)v * MT_N, ext + b);
+  buf.assign(MT_N + DEG + Q + 8, 0);
+  uint32_t *w = buf.data();                                    // the accumulator starts at zero
+  bool zero = true;
+  int i = top;
+  while (i >= 0) {
+    if (!bit(g, i)) {
+      if (!zero) { w[MT_N] = w[MT_M] ^ twist(w[0], w[1]); ++w; }
+      --i;
+      continue;
+    }
+    int l = i + 1 < Q ? i + 1 : Q;
+    while (!bit(g, i - l + 1)) --l;                            // the run ends with a 1 (l >= 1: bit i is set)
+    int v = 0;
+    for (int b = 0; b < l; ++b) v |= bit(g, i - l + 1 + b) << b;
+    if (!zero)
+      for (int k = 0; k < l; ++k) { w[MT_N] = w[MT_M] ^ twist(w[0], w[1]); ++w; }
+    xor_state(w, tab.data() + (size_t)v * MT_N);
+    zero = false;
+    i -= l;
+  }
+  memcpy(s, w, MT_N * sizeof(uint32_t));
+}
+
+constexpr int64_t JUMP_MIN_BLOCKS = 4096;      // below this the direct skip (37 ns per block) is faster
+struct Entry {
+  int64_t blocks = -1;
+  int seen = 0;
+  bool ready = false;
+  uint64_t g[PW];
+};
+Entry g_cache[4];
+std::mutex g_mu;
+
+// r regenerations of s; returns false when the direct skip should be used
+bool regen_many(uint32_t *s, int64_t r) {
+  if (r < JUMP_MIN_BLOCKS || getenv("TRL_MT_NO_JUMP")) return false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_phi_ok) {
+    static bool tried = false;
+    if (tried) return false;
+    tried = true;
+    g_phi_ok = build_phi();
+    if (!g_phi_ok) return false;
+  }
+  Entry *e = nullptr, *victim = &g_cache[0];
+  for (Entry &c : g_cache) {
+    if (c.blocks == r) e = &c;
+    if (c.seen < victim->seen) victim = &c;
+  }
+  if (!e) {
+    e = victim;
+    e->blocks = r;
+    e->seen = 0;
+    e->ready = false;
+  }
+  if (!e->ready) {
+    if (++e->seen < 3) return false;           // not a steady state yet (the ring is still filling)
+    pow_x((uint64_t)(r - 1) * MT_N, e->g);
+    e->ready = true;
+  }
+  ++e->seen;
+  apply(e->g, s);                              // r - 1 blocks ahead, exact on every bit the next step reads
+  mt_regen(s);                                 // the r-th block, by the recurrence itself
+  return true;
+}
+}  // namespace jump
+
+bool jump_regen_many(uint32_t *s, int64_t r) { return jump::regen_many(s, r); }
 
 // open-addressing map position -> value for the sparse permutation
 struct Sparse {
