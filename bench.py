@@ -177,7 +177,7 @@ def bench_ppo(args, rank, world, dev):
   # 65,536 = 128 per epoch were the earlier defaults; DESIGN.md section 5 lists all three)
   B = args.minibatch or max(1, (T * N) // 8)
   steps = args.steps if args.steps is not None else 5
-  warmup = args.warmup if args.warmup is not None else 1
+  warmup = args.warmup if args.warmup is not None else 2
   torch.manual_seed(0)
   ctl = PPOController(obs_size, act_size, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3,
                       clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden, graph=args.use_graph)
@@ -410,8 +410,10 @@ def gather_roofline(dev, iters, rows, B, atari):
 
 # ------------------------------------------------------------------------------ DDPG / DQN learner loops
 def bench_offpolicy(args, rank, world, dev, atari):
-  steps = args.steps if args.steps is not None else 200
-  warmup = args.warmup if args.warmup is not None else 20
+  steps = args.steps if args.steps is not None else 400
+  # the first ~0.1 s of host-bound stepping on a fresh box runs at half speed (seen on every first run of a
+  # gpurun call, whatever the workload): warm up past it
+  warmup = args.warmup if args.warmup is not None else 400
   if not args.no_gemm_tuning:
     from torchrl_amd.tuning import enable_gemm_tuning
     enable_gemm_tuning()     # 32-256-row GEMMs: the BLAS default pick is 4-5x off its best kernel
