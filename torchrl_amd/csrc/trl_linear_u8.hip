@@ -188,6 +188,28 @@ __global__ __launch_bounds__(256) void k_lin_u8_wgrad(WgradArgs a) {
   const int kcol = blockIdx.x * 128 + 4 * i;
   const int kc = kcol < a.K ? kcol : a.K - 4;          // K % 4 == 0: a valid dword either way
   const float *gp = a.g + (size_t)(16 * h) * a.N + n0 + i;
+  const int nblk = a.B / 32;
+  if (blockIdx.x >= (unsigned)((a.K + 127) / 128)) {
+    // one extra workgroup per 128 output rows: the bias gradient (column sums of g), beside the MFMA
+    // workgroups instead of behind one of them.  The two lane halves take alternate 16-row groups of
+    // the batch, added in a fixed order.
+    float sum = 0.f;
+    for (int bb = 0; bb < nblk; ++bb) {
+      const float *g2 = gp + (size_t)bb * 32 * a.N;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = g2[(size_t)j * a.N];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum += v[j];
+    }
+    const float other = __shfl_xor(sum, 32, 64);
+    if (h == 0) {
+      const int n = n0 + i;
+      a.db[n] = sum + other;
+      if (a.update) trl_adam_elem(a.pb + n, a.db + n, a.mb + n, a.vb + n, a.s);
+    }
+    return;
+  }
   const uint8_t *xp = a.x + (size_t)(16 * h) * a.K + kc;
   f16v acc[4];
 #pragma unroll
@@ -196,7 +218,6 @@ __global__ __launch_bounds__(256) void k_lin_u8_wgrad(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float ga[16], gn[16];
   unsigned int xa[16], xn[16];
-  const int nblk = a.B / 32;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     ga[j] = gp[(size_t)j * a.N];
@@ -236,22 +257,6 @@ __global__ __launch_bounds__(256) void k_lin_u8_wgrad(WgradArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) trl_adam_elem(a.pw + off + c, a.dw + off + c, a.mw + off + c, a.vw + off + c, a.s);
       }
-    }
-  }
-  // bias gradient of this wave's 32 output rows: column sums of g, by the workgroups of the first k block;
-  // the two lane halves take alternate 16-row groups of the batch, added in a fixed order
-  if (a.db != nullptr && blockIdx.x == 0) {
-    float sum = 0.f;
-    for (int bb = 0; bb < nblk; ++bb) {
-      const float *g2 = gp + (size_t)bb * 32 * a.N;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) sum += g2[(size_t)j * a.N];
-    }
-    const float other = __shfl_xor(sum, 32, 64);
-    if (h == 0) {
-      const int n = n0 + i;
-      a.db[n] = sum + other;
-      if (a.update) trl_adam_elem(a.pb + n, a.db + n, a.mb + n, a.vb + n, a.s);
     }
   }
 }
@@ -330,7 +335,7 @@ int trl_u8_wgrad_launch(const char *fn, const float *g, const uint8_t *x, int64_
     a.update = 1;
     a.pw = u->pw; a.mw = u->mw; a.vw = u->vw; a.pb = u->pb; a.mb = u->mb; a.vb = u->vb; a.s = u->s;
   }
-  hipLaunchKernelGGL(k_lin_u8_wgrad, dim3((unsigned)trl_cdiv(K, 128), N / 128), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_lin_u8_wgrad, dim3((unsigned)trl_cdiv(K, 128) + (db ? 1 : 0), N / 128), dim3(256), 0, st, a);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
 }
