@@ -239,43 +239,58 @@ __device__ __forceinline__ void fwd_layer1(f32x16 (&h2)[2], const f32x16 (&h1)[2
 
 // last layer on the VALU: out[n] = WL[n] . hl + bL[n] (both lane halves end with the row's value)
 template <int NO>
-__device__ __forceinline__ void fwd_last(float (&out)[NO], const f32x16 (&hl)[2], const float *sWL,
-                                         const float *sBL, int half) {
+__device__ __forceinline__ void fwd_last_acc(float (&p)[NO], const f32x16 (&hl)[2], const float *sWL, int half) {
 #pragma unroll
   for (int n = 0; n < NO; ++n) {
-    float p = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
-        p = fmaf(w4.x, hl[kb][4 * q + 0], p);
-        p = fmaf(w4.y, hl[kb][4 * q + 1], p);
-        p = fmaf(w4.z, hl[kb][4 * q + 2], p);
-        p = fmaf(w4.w, hl[kb][4 * q + 3], p);
+        p[n] = fmaf(w4.x, hl[kb][4 * q + 0], p[n]);
+        p[n] = fmaf(w4.y, hl[kb][4 * q + 1], p[n]);
+        p[n] = fmaf(w4.z, hl[kb][4 * q + 2], p[n]);
+        p[n] = fmaf(w4.w, hl[kb][4 * q + 3], p[n]);
       }
-    p += __shfl_xor(p, 32, 64);
-    out[n] = p + sBL[n];
   }
+}
+
+template <int NO>
+__device__ __forceinline__ void fwd_last_finish(float (&out)[NO], const float (&p)[NO], const float *sBL) {
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    const float t = p[n] + __shfl_xor(p[n], 32, 64);
+    out[n] = t + sBL[n];
+  }
+}
+
+template <int NO>
+__device__ __forceinline__ void fwd_last(float (&out)[NO], const f32x16 (&hl)[2], const float *sWL,
+                                         const float *sBL, int half) {
+  float p[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) p[n] = 0.f;
+  fwd_last_acc<NO>(p, hl, sWL, half);
+  fwd_last_finish<NO>(out, p, sBL);
 }
 
 // weights of one network, zero-padded, into LDS, once per workgroup.  Loads first, stores after:
 // every load of a tile is in flight at once (a load -> store loop pays the L2 latency per iteration)
-template <int D, int LDW0, int NO, bool WITH_T>
+template <int D, int LDW0, int NO, bool WITH_T, int HB = 1>
 __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, float *sW1, float *sW1T, float *sWL,
                                               float *sB, int tid) {
   const int K0 = a.dims[0], H1 = a.dims[1], HL = a.dims[D - 1], NOr = a.dims[D];
   {
-    constexpr int N0 = (64 * LDW0 + 255) / 256;
+    constexpr int N0 = (HB * 64 * LDW0 + 255) / 256;
     float v[N0];
 #pragma unroll
     for (int i = 0; i < N0; ++i) {
-      const int e = tid + 256 * i, n = e / LDW0, k = e % LDW0;
-      v[i] = (n < H1 && k < K0 && e < 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
+      const int e = tid + 256 * i, n = e / LDW0, k = e % LDW0;      // n = q * 64 + local feature
+      v[i] = (n < H1 && k < K0 && e < HB * 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < N0; ++i)
-      if (tid + 256 * i < 64 * LDW0) sW0[tid + 256 * i] = v[i];
+      if (tid + 256 * i < HB * 64 * LDW0) sW0[tid + 256 * i] = v[i];
   }
   if (D == 3) {
     const int H2 = a.dims[2];
@@ -293,15 +308,17 @@ __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, floa
       if (WITH_T) sW1T[k * LDW + n] = v[i];
     }
   }
-  for (int e = tid; e < NO * 64; e += 256) {
-    const int n = e >> 6, k = e & 63;
+  // last layer: block q of the hidden features at sWL + q * NO * 64, [n][64] each
+  for (int e = tid; e < HB * NO * 64; e += 256) {
+    const int q = e / (NO * 64), r = e - q * NO * 64, n = r >> 6, k = q * 64 + (r & 63);
     sWL[e] = (n < NOr && k < HL) ? a.w[D - 1][n * HL + k] : 0.f;
   }
-  for (int e = tid; e < 2 * 64 + 4; e += 256) {
+  // biases: b0 (HB * 64), b1 (64), bL (4)
+  for (int e = tid; e < HB * 64 + 64 + 4; e += 256) {
     float v = 0.f;
-    if (e < 64) v = e < H1 ? a.b[0][e] : 0.f;
-    else if (e < 128) v = (D == 3 && e - 64 < a.dims[2]) ? a.b[1][e - 64] : 0.f;
-    else v = e - 128 < NOr ? a.b[D - 1][e - 128] : 0.f;
+    if (e < HB * 64) v = e < H1 ? a.b[0][e] : 0.f;
+    else if (e < HB * 64 + 64) v = (D == 3 && e - HB * 64 < a.dims[2]) ? a.b[1][e - HB * 64] : 0.f;
+    else v = e - HB * 64 - 64 < NOr ? a.b[D - 1][e - HB * 64 - 64] : 0.f;
     sB[e] = v;
   }
 }
@@ -309,17 +326,22 @@ __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, floa
 // D = depth (2: in -> H -> out, 3: in -> H -> H -> out); KB0 = 32-blocks of the fan-in;
 // NO = padded fan-out of the last layer (actual fan-outs <= NO)
 // XP: the strip's observations are prefetched into registers (fan-in <= 12)
-template <int D, int KB0, int NO, bool XP>
+// HB = 64-wide blocks of the hidden layer: 1 everywhere except the one-hidden-layer case (D == 2) with a
+// fan-in of at most 4, where a hidden layer of up to 256 units (the reference's own ActorCriticNet / A2CNet
+// width, ppo_controller.py:14) is walked block by block inside the wave: that shape has no square product at
+// all, only layer 0, the last layer's dot product and their transposes, each per block.
+template <int D, int KB0, int NO, bool XP, int HB = 1>
 __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
+  static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;             // floats of the x tile (+ a dummy slot for idle prefetch lanes)
   constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0);   // per-wave scratch
   constexpr int WTP = (WT + 3) & ~3;
-  __shared__ __align__(16) float sW0[64 * LDW0];
+  __shared__ __align__(16) float sW0[HB * 64 * LDW0];
   __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];    // W1[n][k]
   __shared__ __align__(16) float sW1T[D == 3 ? 64 * LDW : 4];   // W1^T: [k][n], the backward's A operand
-  __shared__ __align__(16) float sWL[NO * 64];
-  __shared__ __align__(16) float sB[2 * 64 + 4];     // b0, b1 (padded with zeros), bL
+  __shared__ __align__(16) float sWL[HB * NO * 64];
+  __shared__ __align__(16) float sB[HB * 64 + 64 + 4];   // b0 (HB blocks), b1 (padded with zeros), bL
   __shared__ __align__(16) float sT[4 * WTP];
   static_assert(WTP >= 64 * 32 * KB0 && (D == 2 || WTP >= 64 * 64) && 4 * WTP >= 4 * 12 * 64 + 64,
                 "the end-of-kernel reduction re-uses the per-wave scratch");
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int A = P.A;
 
   STAMP(0);
-  stage_weights<D, LDW0, NO, true>(a, sW0, sW1, sW1T, sWL, sB, tid);
+  stage_weights<D, LDW0, NO, true, HB>(a, sW0, sW1, sW1T, sWL, sB, tid);
   float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
   float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
   float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T
@@ -345,11 +367,17 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // ---- per-wave persistent state
   f32x16 accW0[2][KB0];
   f32x16 accW1[2][2];
-  float vdb0 = 0.f, vdb1 = 0.f;     // bias gradients of feature `lane`: row sums of the g tiles
+  float vdb0[HB], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
   // fan-in <= 4: dW0[lane][k] accumulates per lane on the VALU (row_sum32_dw4) instead of in accW0
-  const bool w0v = KB0 == 1 && XP && a.dims[0] <= 4;
-  float dw0v[4] = {0.f, 0.f, 0.f, 0.f};
-  f32x16 dWL[NO][2];
+  const bool w0v = HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
+  float dw0v[HB][4];
+  f32x16 dWL[HB][NO][2];
+#pragma unroll
+  for (int qb = 0; qb < HB; ++qb) {
+    vdb0[qb] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dw0v[qb][k] = 0.f;
+  }
   float dbL[NO];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -366,9 +394,11 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   for (int n = 0; n < NO; ++n) {
     dbL[n] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int qb = 0; qb < HB; ++qb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dWL[n][kb][r] = 0.f;
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dWL[qb][n][kb][r] = 0.f;
   }
   float s_main = 0.f, s_ent = 0.f;
   float s_dls[NO];
@@ -474,14 +504,26 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     PH(6);
 
     // ---- forward: h1, (h2), out
-    f32x16 h1[2], h2[2];
-    fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
-    PH(7);
-    if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
-    PH(8);
-    const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
+    f32x16 h1q[HB][2], h2[2];
+    f32x16 (&h1)[2] = h1q[0];
     float out[NO];
-    fwd_last<NO>(out, hl, sWL, sB + 128, half);
+    {
+      float pacc[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) pacc[n] = 0.f;
+#pragma unroll
+      for (int qb = 0; qb < HB; ++qb) fwd_layer0<LDW0>(h1q[qb], sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
+      PH(7);
+      if (D == 3) {
+        fwd_layer1(h2, h1, sW1, sB + HB * 64, half, r32);
+        fwd_last_acc<NO>(pacc, h2, sWL, half);
+      } else {
+#pragma unroll
+        for (int qb = 0; qb < HB; ++qb) fwd_last_acc<NO>(pacc, h1q[qb], sWL + qb * NO * 64, half);
+      }
+      PH(8);
+      fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
+    }
 
     PH(0);
     // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
@@ -572,6 +614,13 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       }
     }
 
+#pragma unroll
+    for (int n = 0; n < NO; ++n)
+      if (half == 0) dbL[n] += gout[n];
+#pragma unroll
+    for (int qb = 0; qb < HB; ++qb) {     // one pass per 64-wide block of the hidden layer (HB > 1: D == 2)
+    const f32x16 (&hl)[2] = D == 3 ? h2 : h1q[qb];
+    const float *sWLq = sWL + qb * NO * 64;
     // ---- last layer backward (VALU): dWL, dbL partials; g = (WL^T gout) * (hl > 0)
     f32x16 g[2];
 #pragma unroll
@@ -581,20 +630,17 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int n = 0; n < NO; ++n) {
-          const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
+          const float4 w4 = *(const float4 *)(sWLq + n * 64 + kb * 32 + 8 * q + 4 * half);
           t[0] = fmaf(w4.x, gout[n], t[0]);
           t[1] = fmaf(w4.y, gout[n], t[1]);
           t[2] = fmaf(w4.z, gout[n], t[2]);
           t[3] = fmaf(w4.w, gout[n], t[3]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dWL[n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[n][kb][4 * q + i]);
+          for (int i = 0; i < 4; ++i) dWL[qb][n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[qb][n][kb][4 * q + i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = hl[kb][4 * q + i] > 0.f ? t[i] : 0.f;
       }
-#pragma unroll
-    for (int n = 0; n < NO; ++n)
-      if (half == 0) dbL[n] += gout[n];
 
     PH(1);
     // ---- layer 1 backward (D == 3): dW1 += g h1^T (rows through LDS), g <- (W1^T g) * (h1 > 0)
@@ -664,7 +710,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     wave_lds_fence();
     PH(9);
     if (w0v) {
-      vdb0 += row_sum32_dw4(sG + lane * LDT, sX, dw0v);
+      vdb0[qb] += row_sum32_dw4(sG + lane * LDT, sX, dw0v[qb]);
     } else {
       const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
       float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), xv[KB0];
@@ -692,9 +738,10 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) xv[kb] = nx[kb];
       }
-      vdb0 += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
+      vdb0[0] += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
     }
-    wave_lds_fence();     // the next strip overwrites sX / sG
+    wave_lds_fence();     // the next block / strip overwrites sG (and sX)
+    }                     // hidden blocks
     PH(3);
   }
   PH_OUT;
@@ -706,19 +753,21 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 
   // per-lane partial vectors dWL[n] -> per-feature sums over the wave's 32 rows: transposed
   // through the wave's own tile (the bias gradients vdb0 / vdb1 are per feature already)
-  const float vec_db0 = vdb0, vec_db1 = vdb1;
-  float vec_wl[NO];
+  const float vec_db1 = vdb1;
+  float vec_wl[HB][NO];
   {
     float s;
 #pragma unroll
-    for (int n = 0; n < NO; ++n) {
-      put_tile(sG, dWL[n], half, r32);
-      wave_lds_fence();
-      s = 0.f;
-      for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
-      vec_wl[n] = s;
-      wave_lds_fence();
-    }
+    for (int qb = 0; qb < HB; ++qb)
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        put_tile(sG, dWL[qb][n], half, r32);
+        wave_lds_fence();
+        s = 0.f;
+        for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
+        vec_wl[qb][n] = s;
+        wave_lds_fence();
+      }
   }
   // scalars: wave sums (fixed butterfly order)
   float sc[2 + 2 * NO];
@@ -764,31 +813,35 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   constexpr int VS = 12;     // slots per wave: db0, db1, NO last-layer rows, 4 dW0 columns (w0v)
   static_assert(2 + NO + 4 <= VS, "vector slots");
   float *vsum = sT, *scal = sT + 4 * VS * 64;
-  vsum[(wave * VS + 0) * 64 + lane] = vec_db0;
-  vsum[(wave * VS + 1) * 64 + lane] = vec_db1;
-#pragma unroll
-  for (int n = 0; n < NO; ++n) vsum[(wave * VS + 2 + n) * 64 + lane] = vec_wl[n];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) vsum[(wave * VS + 2 + NO + k) * 64 + lane] = dw0v[k];
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
   }
-  __syncthreads();
-  for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += 4) {
-    const int f = tid & 63;
-    const float v = ((vsum[(0 * VS + sl) * 64 + f] + vsum[(1 * VS + sl) * 64 + f]) + vsum[(2 * VS + sl) * 64 + f]) +
-                    vsum[(3 * VS + sl) * 64 + f];
-    if (sl >= 2 + NO) {
-      const int k = sl - 2 - NO;
-      if (f < H1 && k < K0) part[a.poff[0] + f * K0 + k] = v;
-    } else if (sl == 0) {
-      if (f < H1) part[a.poff[0] + H1 * K0 + f] = v;
-    } else if (sl == 1) {
-      if (D == 3 && f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
-    } else {
-      const int n = sl - 2;
-      if (f < HL && n < NOr) part[a.poff[D - 1] + n * HL + f] = v;
+#pragma unroll
+  for (int qb = 0; qb < HB; ++qb) {          // one round per 64-wide block of the hidden layer
+    if (qb) __syncthreads();                 // the previous round's sums are out
+    vsum[(wave * VS + 0) * 64 + lane] = vdb0[qb];
+    vsum[(wave * VS + 1) * 64 + lane] = vec_db1;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) vsum[(wave * VS + 2 + n) * 64 + lane] = vec_wl[qb][n];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vsum[(wave * VS + 2 + NO + k) * 64 + lane] = dw0v[qb][k];
+    __syncthreads();
+    for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += 4) {
+      const int f = tid & 63, fq = qb * 64 + f;
+      const float v = ((vsum[(0 * VS + sl) * 64 + f] + vsum[(1 * VS + sl) * 64 + f]) + vsum[(2 * VS + sl) * 64 + f]) +
+                      vsum[(3 * VS + sl) * 64 + f];
+      if (sl >= 2 + NO) {
+        const int k = sl - 2 - NO;
+        if (fq < H1 && k < K0) part[a.poff[0] + fq * K0 + k] = v;
+      } else if (sl == 0) {
+        if (fq < H1) part[a.poff[0] + H1 * K0 + fq] = v;
+      } else if (sl == 1) {
+        if (D == 3 && f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
+      } else {
+        const int n = sl - 2;
+        if (fq < HL && n < NOr) part[a.poff[D - 1] + n * HL + fq] = v;
+      }
     }
   }
   if (tid < 2 + 2 * NO) {
@@ -814,14 +867,15 @@ struct InferArgs {
   float *value, *mean, *logp;
 };
 
-template <int D, int KB0, int NO, bool XP>
+template <int D, int KB0, int NO, bool XP, int HB = 1>     // HB: as in k_ac_learn
 __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
+  static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;
-  __shared__ __align__(16) float sW0[64 * LDW0];
+  __shared__ __align__(16) float sW0[HB * 64 * LDW0];
   __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];
-  __shared__ __align__(16) float sWL[NO * 64];
-  __shared__ __align__(16) float sB[2 * 64 + 4];
+  __shared__ __align__(16) float sWL[HB * NO * 64];
+  __shared__ __align__(16) float sB[HB * 64 + 64 + 4];
   __shared__ __align__(16) float sT[4 * XT];
   const int net = P.which[blockIdx.y];
   const NetArgs &a = P.net[net];
@@ -829,7 +883,7 @@ __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
   const int K0 = a.dims[0];
   const int64_t B = P.B;
   const int A = P.A;
-  stage_weights<D, LDW0, NO, false>(a, sW0, sW1, nullptr, sWL, sB, tid);
+  stage_weights<D, LDW0, NO, false, HB>(a, sW0, sW1, nullptr, sWL, sB, tid);
   float *sX = sT + wave * XT;
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;
   __syncthreads();
@@ -911,11 +965,20 @@ __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
     fetch(strip + sstride);
     wave_lds_fence();
     f32x16 h1[2], h2[2];
-    fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
-    if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
-    const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
-    float out[NO];
-    fwd_last<NO>(out, hl, sWL, sB + 128, half);
+    float out[NO], pacc[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) pacc[n] = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < HB; ++qb) {     // the hidden layer block by block: only the dot product's partial sum stays
+      fwd_layer0<LDW0>(h1, sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
+      if (D == 3) {
+        fwd_layer1(h2, h1, sW1, sB + HB * 64, half, r32);
+        fwd_last_acc<NO>(pacc, h2, sWL, half);
+      } else {
+        fwd_last_acc<NO>(pacc, h1, sWL + qb * NO * 64, half);
+      }
+    }
+    fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
     if (valid && half == 0) {
       if (net == 0) {
         P.value[row] = out[0];
@@ -1030,13 +1093,15 @@ __global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_bl
   }
 }
 
-int fill_net(const char *fn, const trl_mlp_desc *d, int out_max, NetArgs *a) {
+int fill_net(const char *fn, const trl_mlp_desc *d, int out_max, NetArgs *a, int hidden_max = 64) {
   TRL_REQUIRE(d != nullptr, "%s: null network description", fn);
   TRL_REQUIRE(d->depth == 2 || d->depth == 3, "%s: depth %d not in {2, 3}", fn, d->depth);
   a->depth = d->depth;
   int off = 0;
   for (int l = 0; l <= d->depth; ++l) {
-    const int lim = l == d->depth ? out_max : 64;
+    // one hidden layer over a fan-in of at most 4: up to 256 units, walked as 64-wide blocks (HB)
+    const int wide = (d->depth == 2 && l == 1 && hidden_max > 64 && d->dims[0] <= 4) ? hidden_max : 64;
+    const int lim = l == d->depth ? out_max : wide;
     TRL_REQUIRE(d->dims[l] >= 1 && d->dims[l] <= lim, "%s: dims[%d]=%d must be in [1, %d]", fn, l, d->dims[l], lim);
     a->dims[l] = d->dims[l];
   }
@@ -1105,9 +1170,9 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   TRL_REQUIRE(critic && actor, "%s: null network description", fn);
   TRL_REQUIRE(A <= 2 || actor->depth == 2, "%s: two hidden layers take an action size of at most 2 (got %d)", fn, A);
   LearnArgs P{};
-  int rc = fill_net(fn, critic, 1, &P.net[0]);
+  int rc = fill_net(fn, critic, 1, &P.net[0], 256);
   if (rc) return rc;
-  rc = fill_net(fn, actor, A, &P.net[1]);
+  rc = fill_net(fn, actor, A, &P.net[1], 256);
   if (rc) return rc;
   TRL_REQUIRE(P.net[1].dims[actor->depth] == A, "%s: the actor's fan-out %d is not the action size %d", fn,
               P.net[1].dims[actor->depth], A);
@@ -1153,10 +1218,20 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
     if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_learn<d, kb, no, kb == 1>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_learn<d, kb, no, false>), grid, block, 0, st, P);               \
   }
+  const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
+  if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
+    // (4 blocks x 2 outputs would need 256 accumulator registers for the last layer's gradient alone)
+    TRL_REQUIRE(NOv == 1 || (NOv == 2 && hmax <= 128),
+                "%s: a hidden layer of %d units takes an action size of at most %d (got %d)", fn, hmax, hmax <= 128 ? 2 : 1, A);
+    if (hmax <= 128 && NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 2>), grid, block, 0, st, P);
+    else if (hmax <= 128) hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 2>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 4>), grid, block, 0, st, P);
+  } else {
   TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
   TRL_LEARN_CASE(2, 2, 1) TRL_LEARN_CASE(2, 2, 2) TRL_LEARN_CASE(2, 2, 4)
   TRL_LEARN_CASE(3, 1, 1) TRL_LEARN_CASE(3, 1, 2)
   TRL_LEARN_CASE(3, 2, 1) TRL_LEARN_CASE(3, 2, 2)
+  }
 #undef TRL_LEARN_CASE
   TRL_CHECK_LAUNCH(fn);
   const int np_max = R.nparams[0] > R.nparams[1] ? R.nparams[0] : R.nparams[1];
@@ -1199,14 +1274,14 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
   InferArgs P{};
   int ny = 0, D = 0, K0 = 0;
   if (value) {
-    int rc = fill_net(fn, critic, 1, &P.net[0]);
+    int rc = fill_net(fn, critic, 1, &P.net[0], 256);
     if (rc) return rc;
     P.which[ny++] = 0;
     D = critic->depth; K0 = critic->dims[0];
   }
   if (want_actor) {
     TRL_REQUIRE(A >= 1 && A <= 4, "%s: action size %d not in [1, 4]", fn, A);
-    int rc = fill_net(fn, actor, A, &P.net[1]);
+    int rc = fill_net(fn, actor, A, &P.net[1], 256);
     if (rc) return rc;
     TRL_REQUIRE(P.net[1].dims[actor->depth] == A, "%s: the actor's fan-out is not the action size %d", fn, A);
     TRL_REQUIRE(!value || (actor->depth == D && actor->dims[0] == K0),
@@ -1227,10 +1302,24 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
     if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_infer<d, kb, no, kb == 1>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_infer<d, kb, no, false>), grid, block, 0, st, P);               \
   }
+  int hmax = 0;
+  for (int i = 0; i < ny; ++i) hmax = P.net[P.which[i]].dims[1] > hmax ? P.net[P.which[i]].dims[1] : hmax;
+  if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): blocks of 64
+    if (hmax <= 128) {
+      if (NOv == 1) hipLaunchKernelGGL((k_ac_infer<2, 1, 1, true, 2>), grid, block, 0, st, P);
+      else if (NOv == 2) hipLaunchKernelGGL((k_ac_infer<2, 1, 2, true, 2>), grid, block, 0, st, P);
+      else hipLaunchKernelGGL((k_ac_infer<2, 1, 4, true, 2>), grid, block, 0, st, P);
+    } else {
+      if (NOv == 1) hipLaunchKernelGGL((k_ac_infer<2, 1, 1, true, 4>), grid, block, 0, st, P);
+      else if (NOv == 2) hipLaunchKernelGGL((k_ac_infer<2, 1, 2, true, 4>), grid, block, 0, st, P);
+      else hipLaunchKernelGGL((k_ac_infer<2, 1, 4, true, 4>), grid, block, 0, st, P);
+    }
+  } else {
   TRL_INFER_CASE(2, 1, 1) TRL_INFER_CASE(2, 1, 2) TRL_INFER_CASE(2, 1, 4)
   TRL_INFER_CASE(2, 2, 1) TRL_INFER_CASE(2, 2, 2) TRL_INFER_CASE(2, 2, 4)
   TRL_INFER_CASE(3, 1, 1) TRL_INFER_CASE(3, 1, 2) TRL_INFER_CASE(3, 1, 4)
   TRL_INFER_CASE(3, 2, 1) TRL_INFER_CASE(3, 2, 2) TRL_INFER_CASE(3, 2, 4)
+  }
 #undef TRL_INFER_CASE
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;

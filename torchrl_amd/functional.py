@@ -507,7 +507,8 @@ def mlp64(x, weights, biases, direct_grads=False):
 
 # ------------------------------------------------------------------------------ fused PPO learner step
 class FusedPpoLearn:
-  """forward + PPO loss + backward of an ActorCriticNet whose stacks are at most 64 wide, as one
+  """forward + PPO loss + backward of an ActorCriticNet whose stacks are at most 64 wide (one hidden
+  layer over <= 4 observations: up to 256 wide), as one
   launch (+ a small reduce): csrc/trl_learn.hip, C ABI trl_ppo_learn_fused.
 
   Built once per controller from the stacks' Linear modules (whose parameters and .grad views live
@@ -530,9 +531,14 @@ class FusedPpoLearn:
       return False
     if critic_lin[0].in_features != actor_lin[0].in_features:
       return False
+    # one hidden layer over a fan-in of at most 4 may be up to 256 wide (the reference's own shape,
+    # ppo_controller.py:14): 128 with two actions, 256 with one (k_ac_learn's HB blocks)
+    wide = 64
+    if len(critic_lin) == 2 and critic_lin[0].in_features <= 4 and A <= 2:
+      wide = 256 if A == 1 else 128
     for lin in (critic_lin, actor_lin):
       for i, m in enumerate(lin):
-        if m.bias is None or m.in_features > 64 or (i + 1 < len(lin) and m.out_features > 64):
+        if m.bias is None or m.in_features > wide or (i + 1 < len(lin) and m.out_features > wide):
           return False
         if m.weight.dtype != torch.float32 or not m.weight.is_cuda:
           return False
