@@ -289,6 +289,11 @@ def bench_ppo(args, rank, world, dev):
                            'us_per_launch': round(us_l, 2), 'flops_per_launch': int(flops),
                            'note': 'forward + PPO loss + backward of critic and actor over one minibatch of %d '
                                    '(exact f32 MFMA); %d FLOP per sample' % (a_[0].shape[0], flops // a_[0].shape[0])}
+    if len(f.critic_lin) == 2:
+      # one hidden layer: no hidden x hidden product; the last layer's dot products, their transposes and
+      # (fan-in <= 4) the layer-0 weight gradient run on the VALU, so the MFMA peak is not this shape's bound
+      res['learn_kernel']['note'] += ('; single hidden layer: most of these FLOPs are VALU FMAs (f32 VALU peak '
+                                      '%.1f TFLOP/s), frac is still quoted against the MFMA peak' % (F32_MFMA_PEAK_TFLOPS / 2))
   return res, dict(T=T, hidden=hidden, B=B, epochs=args.epochs)
 
 
