@@ -22,7 +22,7 @@ CASES = [(3, 1, (64, 64), 65536), (3, 1, (64, 64), 4097), (4, 2, (64, 64), 9000)
          (33, 3, (20,), 300), (3, 1, (64, 64), 256),
          # one hidden layer wider than 64 over <= 4 observations (ppo_controller.py:14 builds 256): hidden blocks
          (3, 1, (256,), 65536), (3, 1, (256,), 4097), (4, 1, (200,), 3000), (4, 2, (128,), 5000), (2, 2, (100,), 900),
-         (3, 1, (96,), 1000), (1, 1, (129,), 2048)]
+         (3, 1, (96,), 1000), (1, 1, (129,), 2048), (4, 2, (256,), 5000), (3, 2, (200,), 999)]
 
 
 def _batch(obs_size, A, B, seed):
@@ -104,14 +104,15 @@ def test_fused_learn_is_reproducible_and_rejects_bad_shapes():
     ctl._fused(obs, act[:100], ret, old, adv, 0.2, 0.5, 1e-3)
   assert PPOController(3, 1, device=DEV, hidden=(128, 64))._fused is None              # too wide: general path
   assert PPOController(3, 3, device=DEV, hidden=(64, 64))._fused is None               # A > 2 with two hidden layers
-  assert PPOController(3, 2, device=DEV, hidden=(256,))._fused is None                 # two actions: 128 at most
+  assert PPOController(3, 3, device=DEV, hidden=(256,))._fused is None                 # wide: two actions at most
   assert PPOController(5, 1, device=DEV, hidden=(256,))._fused is None                 # wide needs a fan-in <= 4
   assert PPOController(3, 1, device=DEV, hidden=(257,))._fused is None
 
 
 @pytest.mark.parametrize('obs_size,A,hidden,B', [(3, 1, (64, 64), 70001), (4, 2, (64, 64), 4096), (40, 2, (48, 33), 999),
                                                  (5, 4, (64,), 12345), (64, 1, (64, 64), 300),
-                                                 (3, 1, (256,), 70001), (4, 2, (128,), 1234), (2, 1, (130,), 333)])
+                                                 (3, 1, (256,), 70001), (4, 2, (128,), 1234), (2, 1, (130,), 333),
+                                                 (4, 2, (256,), 4321)])
 def test_fused_forward_matches_torch(obs_size, A, hidden, B):
   """trl_ppo_forward_fused (value / mean / log-prob, outputs only) vs the torch modules."""
   torch.manual_seed(B)
@@ -152,7 +153,7 @@ def test_compute_return_fused_equals_general_path(monkeypatch):
 
 @pytest.mark.parametrize('obs_size,A,hidden,B', [(4, 2, 64, 9001), (4, 2, (64, 64), 4096), (8, 4, 48, 5000),
                                                  (40, 3, 64, 700), (3, 1, (33, 20), 2048), (4, 2, 128, 9001),
-                                                 (4, 2, 100, 700)])
+                                                 (4, 2, 100, 700), (4, 2, 256, 9001), (4, 2, 180, 1500)])
 def test_fused_a2c_learn_matches_oracle(obs_size, A, hidden, B):
   """trl_a2c_learn_fused vs the oracle's torch-CPU A2CController.learn (a2c_controller.py:47-69):
   softmax actor + Categorical loss, losses to 1e-6 relative, gradients, weights after Adam."""

@@ -367,13 +367,21 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // ---- per-wave persistent state
   f32x16 accW0[2][KB0];
   f32x16 accW1[2][2];
-  float vdb0[HB], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
+  // NBQ: hidden blocks whose backward this workgroup runs.  4 blocks x 2 outputs would need 256 registers for
+  // the last layer's gradient accumulators alone, so that case is launched with gridDim.z = 2: every z runs
+  // the whole forward and the backward of its own two blocks (blocks qb0 .. qb0 + NBQ - 1), recomputing a
+  // block's activations there (RC below) instead of holding all four from the forward; the two z write
+  // disjoint entries of the same partial set, z = 0 also the scalars and the last layer's bias gradient.
+  constexpr int NBQ = HB * NO > 4 ? HB / 2 : HB;
+  constexpr bool RC = NBQ != HB;
+  const int qb0 = RC ? (int)blockIdx.z * NBQ : 0;
+  float vdb0[NBQ], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
   // fan-in <= 4: dW0[lane][k] accumulates per lane on the VALU (row_sum32_dw4) instead of in accW0
   const bool w0v = HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
-  float dw0v[HB][4];
-  f32x16 dWL[HB][NO][2];
+  float dw0v[NBQ][4];
+  f32x16 dWL[NBQ][NO][2];
 #pragma unroll
-  for (int qb = 0; qb < HB; ++qb) {
+  for (int qb = 0; qb < NBQ; ++qb) {
     vdb0[qb] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dw0v[qb][k] = 0.f;
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   for (int n = 0; n < NO; ++n) {
     dbL[n] = 0.f;
 #pragma unroll
-    for (int qb = 0; qb < HB; ++qb)
+    for (int qb = 0; qb < NBQ; ++qb)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -504,7 +512,10 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     PH(6);
 
     // ---- forward: h1, (h2), out
-    f32x16 h1q[HB][2], h2[2];
+    // RC: the blocks' activations are not held from forward to backward but recomputed per block in the
+    // backward (layer 0 over a fan-in <= 4 is two MFMA steps per tile)
+    constexpr int HQ = RC ? 1 : HB;
+    f32x16 h1q[HQ][2], h2[2];
     f32x16 (&h1)[2] = h1q[0];
     float out[NO];
     {
@@ -512,14 +523,17 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
       for (int n = 0; n < NO; ++n) pacc[n] = 0.f;
 #pragma unroll
-      for (int qb = 0; qb < HB; ++qb) fwd_layer0<LDW0>(h1q[qb], sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
+      for (int qb = 0; qb < HB; ++qb) {
+        fwd_layer0<LDW0>(h1q[RC ? 0 : qb], sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
+        if (RC) fwd_last_acc<NO>(pacc, h1q[0], sWL + qb * NO * 64, half);
+      }
       PH(7);
       if (D == 3) {
         fwd_layer1(h2, h1, sW1, sB + HB * 64, half, r32);
         fwd_last_acc<NO>(pacc, h2, sWL, half);
-      } else {
+      } else if (!RC) {
 #pragma unroll
-        for (int qb = 0; qb < HB; ++qb) fwd_last_acc<NO>(pacc, h1q[qb], sWL + qb * NO * 64, half);
+          for (int qb = 0; qb < HB; ++qb) fwd_last_acc<NO>(pacc, h1q[qb], sWL + qb * NO * 64, half);
       }
       PH(8);
       fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
@@ -618,9 +632,10 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     for (int n = 0; n < NO; ++n)
       if (half == 0) dbL[n] += gout[n];
 #pragma unroll
-    for (int qb = 0; qb < HB; ++qb) {     // one pass per 64-wide block of the hidden layer (HB > 1: D == 2)
-    const f32x16 (&hl)[2] = D == 3 ? h2 : h1q[qb];
-    const float *sWLq = sWL + qb * NO * 64;
+    for (int qb = 0; qb < NBQ; ++qb) {    // one pass per 64-wide block of the hidden layer (HB > 1: D == 2)
+    if (RC) fwd_layer0<LDW0>(h1q[0], sX, sW0 + (qb0 + qb) * 64 * LDW0, sB + (qb0 + qb) * 64, ksteps0, half, r32);
+    const f32x16 (&hl)[2] = D == 3 ? h2 : h1q[RC ? 0 : qb];
+    const float *sWLq = sWL + (qb0 + qb) * NO * 64;
     // ---- last layer backward (VALU): dWL, dbL partials; g = (WL^T gout) * (hl > 0)
     f32x16 g[2];
 #pragma unroll
@@ -754,11 +769,11 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // per-lane partial vectors dWL[n] -> per-feature sums over the wave's 32 rows: transposed
   // through the wave's own tile (the bias gradients vdb0 / vdb1 are per feature already)
   const float vec_db1 = vdb1;
-  float vec_wl[HB][NO];
+  float vec_wl[NBQ][NO];
   {
     float s;
 #pragma unroll
-    for (int qb = 0; qb < HB; ++qb)
+    for (int qb = 0; qb < NBQ; ++qb)
 #pragma unroll
       for (int n = 0; n < NO; ++n) {
         put_tile(sG, dWL[qb][n], half, r32);
@@ -818,7 +833,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
   }
 #pragma unroll
-  for (int qb = 0; qb < HB; ++qb) {          // one round per 64-wide block of the hidden layer
+  for (int qb = 0; qb < NBQ; ++qb) {         // one round per 64-wide block of the hidden layer
     if (qb) __syncthreads();                 // the previous round's sums are out
     vsum[(wave * VS + 0) * 64 + lane] = vdb0[qb];
     vsum[(wave * VS + 1) * 64 + lane] = vec_db1;
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     for (int k = 0; k < 4; ++k) vsum[(wave * VS + 2 + NO + k) * 64 + lane] = dw0v[qb][k];
     __syncthreads();
     for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += 4) {
-      const int f = tid & 63, fq = qb * 64 + f;
+      const int f = tid & 63, fq = (qb0 + qb) * 64 + f;
       const float v = ((vsum[(0 * VS + sl) * 64 + f] + vsum[(1 * VS + sl) * 64 + f]) + vsum[(2 * VS + sl) * 64 + f]) +
                       vsum[(3 * VS + sl) * 64 + f];
       if (sl >= 2 + NO) {
@@ -844,7 +859,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       }
     }
   }
-  if (tid < 2 + 2 * NO) {
+  if (tid < 2 + 2 * NO && (!RC || blockIdx.z == 0)) {
     const float v = ((scal[0 * 16 + tid] + scal[1 * 16 + tid]) + scal[2 * 16 + tid]) + scal[3 * 16 + tid];
     if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
       if (tid < 2 + A) part[a.nparams + tid] = v;
@@ -1221,11 +1236,11 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
   if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
     // (4 blocks x 2 outputs would need 256 accumulator registers for the last layer's gradient alone)
-    TRL_REQUIRE(NOv == 1 || (NOv == 2 && hmax <= 128),
-                "%s: a hidden layer of %d units takes an action size of at most %d (got %d)", fn, hmax, hmax <= 128 ? 2 : 1, A);
+    TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
     if (hmax <= 128 && NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 2>), grid, block, 0, st, P);
     else if (hmax <= 128) hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 2>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 4>), grid, block, 0, st, P);
+    else if (NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 4>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 4>), dim3(grid.x, 2, 2), block, 0, st, P);   // NBQ = 2
   } else {
   TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
   TRL_LEARN_CASE(2, 2, 1) TRL_LEARN_CASE(2, 2, 2) TRL_LEARN_CASE(2, 2, 4)

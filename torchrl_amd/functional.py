@@ -531,11 +531,11 @@ class FusedPpoLearn:
       return False
     if critic_lin[0].in_features != actor_lin[0].in_features:
       return False
-    # one hidden layer over a fan-in of at most 4 may be up to 256 wide (the reference's own shape,
-    # ppo_controller.py:14): 128 with two actions, 256 with one (k_ac_learn's HB blocks)
+    # one hidden layer over a fan-in of at most 4 and at most two actions may be up to 256 wide (the
+    # reference's own shape, ppo_controller.py:14 / a2c_controller.py: k_ac_learn's HB blocks)
     wide = 64
     if len(critic_lin) == 2 and critic_lin[0].in_features <= 4 and A <= 2:
-      wide = 256 if A == 1 else 128
+      wide = 256
     for lin in (critic_lin, actor_lin):
       for i, m in enumerate(lin):
         if m.bias is None or m.in_features > wide or (i + 1 < len(lin) and m.out_features > wide):
