@@ -282,8 +282,8 @@ int trl_mlp_bwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *x
  * small fixed-order reduction: a wavefront carries 32 samples from the observation to the
  * parameter-gradient partials with the activations in registers (csrc/trl_learn.hip).
  *   critic, actor: depth 2 or 3 (one or two hidden layers, ReLU between), same depth and fan-in;
- *   a single hidden layer over a fan-in of at most 4 may be up to 256 wide with A = 1 and up to 128
- *   with A = 2 (walked as 64-wide blocks inside the wave), every other width at most 64;
+ *   a single hidden layer over a fan-in of at most 4 may be up to 256 wide with A <= 2 (walked as
+ *   64-wide blocks inside the wave), every other width at most 64;
  *   critic fan-out 1, actor fan-out A (1 <= A <= 4);  log_std [A];  obs [B, fan-in];
  *   action, old_logp [B, A];  returns, adv [B].
  *   losses_out[0..3] = actor, critic, entropy, actor + alpha * critic - beta * entropy.
