@@ -217,3 +217,70 @@ def test_fused_learn_random_shapes(obs_size, A, hidden, B):
   v2, m2, _ = ctl._fused.forward(obs.to(DEV))
   torch.testing.assert_close(v2.cpu(), value.detach().view(-1), rtol=1e-5, atol=3e-6)
   torch.testing.assert_close(m2.cpu(), mean.detach(), rtol=1e-5, atol=3e-6)
+
+
+# ------------------------------------------------------------------ the reference's own outputs through the whole-step kernel
+def _close(got, exp, rtol, atol_frac):
+  exp = np.asarray(exp)
+  np.testing.assert_allclose(np.asarray(got), exp, rtol=rtol, atol=atol_frac * max(1e-30, float(np.abs(exp).max())))
+
+
+def test_fused_ppo_learn_golden_reference_shape(golden):
+  """tests/golden/ppo.npz holds the reference's PPOController.learn outputs (two steps: losses, clipped
+  gradients, weights after Adam) on its own network, ActorCriticNet(3, A, 256) (ppo_controller.py:14).
+  Here they go through the whole-step kernel (its batch threshold, a speed choice, lowered for the
+  fixtures' 5..64-row batches); the A = 3 fixture is outside the kernel's shapes and stays with
+  tests/test_gpu_losses.py."""
+  g = golden('ppo.npz')
+  from tests.helpers import FIELDS, state_from, t
+  ran = 0
+  for ci in range(int(g['n_ppo'])):
+    p = 'ppo%d_' % ci
+    A = g[p + 'net0.log_std'].shape[1]
+    c = PPOController(3, A, lr=3e-4, alpha=0.5, beta=float(g[p + 'beta']), clip_ratio=0.2,
+                      max_grad_norm=float(g[p + 'max_grad_norm']), device=DEV)
+    if A > 2:
+      assert c._fused is None
+      continue
+    assert c._fused is not None
+    c._fused.MIN_BATCH = 1
+    c.ac_net.load_state_dict(state_from(g, p + 'net0'))
+    for step in range(2):
+      names = FIELDS + ('returns', 'old_log_probs', 'advantages')
+      batch = [t(g['%sstep%d_%s' % (p, step, f)], DEV) for f in names]
+      assert c._fused.usable(batch[0])
+      info = c.learn(*batch)
+      for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+        np.testing.assert_allclose(float(info[k].cpu()), float(g['%sstep%d_%s' % (p, step, k)]), rtol=1e-6, atol=2e-7)
+      _close(c._flat.dense(grad=True).cpu().numpy(), g['%sstep%d_grad' % (p, step)], 1e-4, 1e-5)
+      _close(c._flat.dense().cpu().numpy(), g['%sstep%d_net' % (p, step)], 1e-5, 1e-5)
+    ran += 1
+  assert ran >= 3
+
+
+def test_fused_a2c_learn_golden_reference_shape(golden):
+  """tests/golden/a2c.npz: the reference's A2CController.learn on A2CNet(4, 2, 256) (a2c_controller.py:13),
+  through the whole-step kernel's two-output 256-wide variant."""
+  g = golden('a2c.npz')
+  from tests.helpers import FIELDS, state_from, t
+  ran = 0
+  for ci in range(int(g['n_a2c'])):
+    p = 'a2c%d_' % ci
+    A = g[p + 'net0.actor.2.bias'].shape[0]
+    c = A2CController(4, A, lr=1e-3, alpha=0.5, beta=float(g[p + 'beta']), device=DEV)
+    if A > 2:
+      assert c._fused is None
+      continue
+    assert c._fused is not None
+    c._fused.MIN_BATCH = 1
+    c.ac_net.load_state_dict(state_from(g, p + 'net0'))
+    for step in range(2):
+      batch = [t(g['%sstep%d_%s' % (p, step, f)], DEV) for f in FIELDS + ('returns',)]
+      assert c._fused.usable(batch[0])
+      info = c.learn(*batch)
+      for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+        np.testing.assert_allclose(float(info[k].cpu()), float(g['%sstep%d_%s' % (p, step, k)]), rtol=1e-6, atol=2e-7)
+      _close(c._flat.dense(grad=True).cpu().numpy(), g['%sstep%d_grad' % (p, step)], 1e-4, 1e-5)
+      _close(c._flat.dense().cpu().numpy(), g['%sstep%d_net' % (p, step)], 1e-5, 1e-5)
+    ran += 1
+  assert ran >= 1
