@@ -173,6 +173,28 @@ def test_block_of_envs_golden(golden):
   np.testing.assert_allclose(lp3.cpu().numpy().transpose(1, 0, 2), g['blk_log_probs'], rtol=1e-5, atol=1e-5)
 
 
+def test_block_of_envs_golden_through_forward_kernel(golden):
+  """The same reference rollouts with compute_return_batched's value / log-prob pass forced through the
+  forward-only kernel (k_ac_infer, 256-wide hidden blocks: the reference's ActorCriticNet(3, 1, 256))."""
+  g = golden('returns.npz')
+  c = PPOController(3, 1, gamma=float(g['blk_gamma']), lmbda=float(g['blk_lmbda']), device=DEV)
+  assert c._fused is not None
+  c._fused.MIN_BATCH = 1
+  c.ac_net.load_state_dict(state_from(g, 'blk_net'))
+  rew = t(np.ascontiguousarray(np.array(g['blk_reward'])[:, :, 0].T), DEV)
+  obs = t(np.ascontiguousarray(np.array(g['blk_obs']).transpose(1, 0, 2)), DEV)
+  act = t(np.ascontiguousarray(np.array(g['blk_action']).transpose(1, 0, 2)), DEV)
+  last_next = t(np.array(g['blk_next_obs'])[:, -1, :], DEV)
+  done_last = np.array(g['blk_done'])[:, -1, 0]
+  assert c._fused.usable(obs.reshape(-1, 3)) and c._fused.usable(last_next)
+  r3, a3, lp3, v3 = c.compute_return_batched(obs, act, rew, last_next, t(done_last, DEV), env_major_out=True)
+  exp = np.array(g['blk_returns'])[:, :, 0]
+  np.testing.assert_allclose(r3.cpu().numpy(), exp, rtol=1e-5, atol=1e-5 * np.abs(exp).max())
+  np.testing.assert_allclose(lp3.cpu().numpy().transpose(1, 0, 2), g['blk_log_probs'], rtol=1e-5, atol=1e-5)
+  np.testing.assert_allclose(a3.cpu().numpy(), exp - np.array(g['blk_values'])[:, :, 0], rtol=1e-5,
+                             atol=1e-5 * np.abs(exp).max())
+
+
 def test_bad_arguments_raise():
   x = torch.zeros(4, 4, device=DEV)
   with pytest.raises(ValueError):
