@@ -284,3 +284,26 @@ def test_fused_a2c_learn_golden_reference_shape(golden):
       _close(c._flat.dense().cpu().numpy(), g['%sstep%d_net' % (p, step)], 1e-5, 1e-5)
     ran += 1
   assert ran >= 1
+
+
+@pytest.mark.parametrize('A,hidden,B', [(3, 256, 777), (4, 130, 4100)])
+def test_wide_forward_more_actions_and_learn_rejects(A, hidden, B):
+  """The C ABI's forward takes a wide hidden layer with up to 4 actions (the Python classes only route
+  A <= 2 there, where the learn entry follows); the learn entry refuses A > 2 on a wide layer loudly."""
+  torch.manual_seed(A + hidden)
+  ctl = PPOController(4, A, device=DEV, hidden=(hidden,))
+  assert ctl._fused is None
+  lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (ctl.ac_net.critic, ctl.ac_net.actor)]
+  fused = F.FusedPpoLearn(lins[0], lins[1], ctl.ac_net.log_std)
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  obs, act = torch.randn(B, 4), torch.randn(B, A)
+  with torch.no_grad():
+    ev, em = ref.critic(obs), ref.actor(obs)
+    elp = torch.distributions.Normal(em, ref.log_std.exp().expand_as(em)).log_prob(act)
+  value, mean, logp = fused.forward(obs.to(DEV), act.to(DEV))
+  torch.testing.assert_close(value.cpu(), ev.view(-1), rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(mean.cpu(), em, rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(logp.cpu(), elp, rtol=1e-5, atol=1e-5)
+  z = torch.zeros(B, A, device=DEV)
+  with pytest.raises(Exception, match='action size'):
+    fused(obs.to(DEV), act.to(DEV), torch.zeros(B, device=DEV), z, torch.zeros(B, device=DEV), 0.2, 0.5, 1e-3)
