@@ -14,7 +14,12 @@
  *   - `stream` is a hipStream_t (void* here so the header needs no HIP include);
  *     NULL is the legacy default stream.  Nothing here allocates, frees or
  *     synchronises: work is enqueued on `stream` and the call returns.
- *   - thread-compatible: no mutable global state except the thread-local error text.
+ *   - thread-compatible.  Process-wide state is limited to: the thread-local error text; the
+ *     mutex-guarded jump-ahead polynomial cache of trl_randperm_prefix (a pure function of the
+ *     skip length, so it never changes a result); the per-device address of the static scratch
+ *     array of the no-allocation entry point at the end of this header.  Nothing reads the
+ *     environment: tuning / ablation switches exist only in the -DTRL_TUNING diagnostic build
+ *     (torchrl_amd/_build.py --tuning -> lib/libtrl_hip_tune.so, used by tools/ only).
  */
 #ifndef TRL_HIP_H
 #define TRL_HIP_H
@@ -42,6 +47,7 @@ extern "C" {
 /* output layout of the GAE kernel */
 #define TRL_LAYOUT_TN 0 /* [T, N] like the inputs */
 #define TRL_LAYOUT_NT 1 /* [N, T] env-major: the order examples/ppo.py:61-64 concatenates in */
+#define TRL_LAYOUT_BLOCKED 2 /* [N / E][t_stride][E]: E = 8 or 16 consecutive envs x all steps contiguous */
 
 /* loss kinds for the TD kernel */
 #define TRL_LOSS_MSE 0   /* reference: dqn_controller.py:77-78, ddpg_controller.py:112 */
@@ -106,6 +112,11 @@ int trl_gather_range(const void *ring, int64_t capacity, int64_t stride,
 int trl_mt19937_seed(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, uint64_t seed);
 int trl_randperm_prefix(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, int64_t n, int64_t B,
                         int64_t *out_h);
+/* The same result by the plain block-by-block skip only (never the GF(2) jump-ahead, which
+ * trl_randperm_prefix switches to for rings of more than ~2.6 M rows): the yardstick the jump is
+ * tested against, and the form for callers that want no process-wide cache touched. */
+int trl_randperm_prefix_direct(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, int64_t n, int64_t B,
+                               int64_t *out_h);
 
 /* Throughput-mode sampler, on the device: B distinct indices uniform over [0, n) written to
  * idx_d (device int64 [B]), ready for trl_gather_rows -- the same distribution as
@@ -135,6 +146,22 @@ int trl_gae_reverse_scan(const float *reward, const float *value, const float *d
                          const float *bootstrap, int64_t T, int64_t N, double gamma,
                          double lmbda, int32_t mode, int32_t out_layout, float *returns,
                          float *adv, void *stream);
+
+/* The same scan over a rollout kept in the BLOCKED layout: element (t, env) of reward / value / done
+ * is at ((env / E) * in_t_stride + t) * E + env % E floats, E = block_envs (8 or 16), N % E == 0,
+ * in_t_stride >= T the rows allocated per env group (0 = T).  A workgroup's E envs x T steps are then
+ * one contiguous run per plane (flat-stream geometry) instead of a 4 * E-byte segment of every [T, N]
+ * row.  This is the layout torchrl_amd's RolloutBuffer(layout='blocked') appends env steps in and the
+ * forward-only value kernel writes its values in; there is no reference counterpart (the reference
+ * keeps one [T, .] buffer per env, examples/ppo.py:28-35).  Arithmetic and results are those of
+ * trl_gae_reverse_scan element for element.  out_layout: TRL_LAYOUT_BLOCKED (same indexing with
+ * out_t_stride, 0 = T) or TRL_LAYOUT_NT (env-major [N, T], the reference's minibatch order).
+ * bootstrap stays [N].  Every plane must be 16-byte aligned. */
+int trl_gae_reverse_scan_blocked(const float *reward, const float *value, const float *done,
+                                 const float *bootstrap, int64_t T, int64_t N, int32_t block_envs,
+                                 int64_t in_t_stride, double gamma, double lmbda, int32_t mode,
+                                 int32_t out_layout, int64_t out_t_stride, float *returns, float *adv,
+                                 void *stream);
 
 /* ------------------------------------------------------------------ fused losses (a-4)
  * Workspace: every loss kernel reduces over the batch in two fixed-order stages, so

@@ -90,18 +90,15 @@ def test_generator_argument():
   assert torch.equal(torch.rand(3, generator=g1), torch.rand(3, generator=g2))
 
 
-def test_sampler_jump_ahead_equals_direct_skip_and_torch(monkeypatch):
+def test_sampler_jump_ahead_equals_direct_skip_and_torch():
   """Rings of more than ~2.6 M rows skip their n - 1 - B unused words by polynomial jump-ahead once the
   same skip length has been seen three times (csrc/trl_host.cpp, namespace jump).  Same indices, same
   generator state as the block-by-block skip, and as torch.randperm itself."""
   from torchrl_amd.utils.sampler import Mt19937Sampler, randperm_prefix
   n, B = 2_700_001, 48
   jumped, direct = Mt19937Sampler(31), Mt19937Sampler(31)
-  monkeypatch.delenv('TRL_MT_NO_JUMP', raising=False)
   a = [jumped.randperm_prefix(n, B).numpy().copy() for _ in range(8)]
-  monkeypatch.setenv('TRL_MT_NO_JUMP', '1')
-  b = [direct.randperm_prefix(n, B).numpy().copy() for _ in range(8)]
-  monkeypatch.delenv('TRL_MT_NO_JUMP')
+  b = [direct.randperm_prefix(n, B, jump=False).numpy().copy() for _ in range(8)]
   for x, y in zip(a, b):
     np.testing.assert_array_equal(x, y)
   np.testing.assert_array_equal(jumped._mt, direct._mt)

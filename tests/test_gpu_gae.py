@@ -195,6 +195,85 @@ def test_block_of_envs_golden_through_forward_kernel(golden):
                              atol=1e-5 * np.abs(exp).max())
 
 
+def _run_blocked(reward, value, boot, gamma, lmbda, E, cap=None, **kw):
+  """reward / value [T, N] numpy -> blocked device planes (optionally inside a [G, cap, E] buffer)."""
+  T, N = reward.shape
+  planes = []
+  for x in (reward, value) + ((kw.pop('done_np'),) if 'done_np' in kw else ()):
+    b = F.to_blocked(torch.from_numpy(x).to(DEV), E)
+    if cap is not None:
+      buf = torch.full((N // E, cap, E), float('nan'), device=DEV)
+      buf[:, :T] = b
+      b = buf[:, :T]
+    planes.append(b)
+  if len(planes) == 3:
+    kw['done'] = planes[2]
+  r, a = F.gae_blocked(planes[0], planes[1], torch.from_numpy(boot).to(DEV), gamma, lmbda, **kw)
+  torch.cuda.synchronize()
+  return r, a
+
+
+@pytest.mark.parametrize('E', [8, 16])
+@pytest.mark.parametrize('T,N', [(1, 16), (5, 16), (63, 32), (64, 48), (65, 16), (129, 64), (300, 1008), (2048, 48),
+                                 (64, 8192), (257, 4096 + 16)])
+def test_blocked_layout_vs_oracle_bitwise(T, N, E):
+  """The blocked rollout layout [N / E][T][E] (flat per-group streams) gives the oracle's numbers bit for bit,
+  written blocked or env-major, also when the planes are [:, :T] slices of a larger-capacity buffer."""
+  rs = np.random.RandomState(T * 17 + N + E)
+  reward, value = rs.randn(T, N).astype(np.float32), rs.randn(T, N).astype(np.float32)
+  boot = rs.randn(N).astype(np.float32)
+  boot[::5] = 0.0
+  exp_r, exp_a = gae_oracle.gae_numpy(reward, value, boot, 0.99, 0.95)
+  for cap in (None, T + 37):
+    r, a = _run_blocked(reward, value, boot, 0.99, 0.95, E, cap=cap)
+    assert r.shape == (N // E, T, E)
+    np.testing.assert_array_equal(F.from_blocked(r).cpu().numpy(), exp_r)
+    np.testing.assert_array_equal(F.from_blocked(a).cpu().numpy(), exp_a)
+    r, a = _run_blocked(reward, value, boot, 0.99, 0.95, E, cap=cap, env_major_out=True)
+    np.testing.assert_array_equal(r.cpu().numpy(), exp_r.T)
+    np.testing.assert_array_equal(a.cpu().numpy(), exp_a.T)
+
+
+@pytest.mark.parametrize('E', [8, 16])
+def test_blocked_full_size_config2(E):
+  """BASELINE config 2 (T=2048, N=4096) in the blocked layout: bit-identical to the [T, N] parity mode."""
+  T, N = 2048, 4096
+  rs = np.random.RandomState(0)
+  reward, value = rs.randn(T, N).astype(np.float32), rs.randn(T, N).astype(np.float32)
+  boot = rs.randn(N).astype(np.float32)
+  exp_r, exp_a = gae_oracle.gae_numpy(reward, value, boot, 0.99, 0.95)
+  r, a = _run_blocked(reward, value, boot, 0.99, 0.95, E)
+  np.testing.assert_array_equal(F.from_blocked(r).cpu().numpy(), exp_r)
+  np.testing.assert_array_equal(F.from_blocked(a).cpu().numpy(), exp_a)
+  tn_r, tn_a = _run(reward, value, boot, 0.99, 0.95)
+  np.testing.assert_array_equal(F.from_blocked(r).cpu().numpy(), tn_r)
+  np.testing.assert_array_equal(F.from_blocked(a).cpu().numpy(), tn_a)
+
+
+@pytest.mark.parametrize('E', [8, 16])
+def test_blocked_masked_mode(E):
+  T, N = 263, 1024
+  rs = np.random.RandomState(5)
+  reward, value = rs.randn(T, N).astype(np.float32), rs.randn(T, N).astype(np.float32)
+  boot = rs.randn(N).astype(np.float32)
+  done = (rs.rand(T, N) < 0.05).astype(np.float32)
+  exp_r, exp_a = gae_oracle.gae_numpy(reward, value, boot, 0.99, 0.95, done=done, masked=True)
+  r, a = _run_blocked(reward, value, boot, 0.99, 0.95, E, done_np=done, masked=True)
+  np.testing.assert_array_equal(F.from_blocked(r).cpu().numpy(), exp_r)
+  np.testing.assert_array_equal(F.from_blocked(a).cpu().numpy(), exp_a)
+
+
+def test_blocked_bad_arguments_raise():
+  x = torch.zeros(4, 6, 16, device=DEV)
+  with pytest.raises(ValueError):
+    F.gae_blocked(x, x, torch.zeros(63, device=DEV), 0.99, 0.95)          # bootstrap is not [N]
+  with pytest.raises(ValueError):
+    F.gae_blocked(x.transpose(0, 1), x.transpose(0, 1), torch.zeros(96, device=DEV), 0.99, 0.95)   # not group-contiguous
+  with pytest.raises(ValueError):
+    F.gae_blocked(torch.zeros(4, 6, 12, device=DEV), torch.zeros(4, 6, 12, device=DEV), torch.zeros(48, device=DEV),
+                  0.99, 0.95)                                               # 12 envs per group
+
+
 def test_bad_arguments_raise():
   x = torch.zeros(4, 4, device=DEV)
   with pytest.raises(ValueError):

@@ -15,6 +15,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('TRL_LIB', 'tune')   # the -DTRL_TUNING diagnostic build (python -m torchrl_amd._build --tuning)
 from torchrl_amd import functional as F  # noqa: E402
 
 
@@ -56,6 +57,8 @@ def main():
   print('torch copy r -> ret (8 B/elem): %.1f us  %.0f GB/s' % (us, 8 * T * N / us / 1e3))
   configs = [(16, PF, d, 2) for PF in (2, 3) for d in (0, 1, 2, 3, 8, 9, 10, 11)] + [(32, 2, 0, 2), (32, 3, 0, 2)]
   configs += [(16, PF, d, 1) for PF in (2, 3, 4) for d in (0, 1, 11)]
+  if '--blocked' in sys.argv:
+    configs = [(16, 2, 0, 1), (16, 2, 16, 1), (16, 2, 32, 1), (16, 2, 48, 1)]
   for E, PF, dbg, U in configs:
     os.environ['TRL_GAE_TUNE'] = '%d,%d,%d,%d' % (E, PF, dbg, U)
     try:
@@ -65,6 +68,38 @@ def main():
       continue
     print('E=%2d PF=%d dbg=%2d U=%d  %7.1f us %6.0f GB/s' % (E, PF, dbg, U, us, algo / us / 1e3), flush=True)
   os.environ.pop('TRL_GAE_TUNE')
+  # ---- blocked layout [N / E][T][E]: the same kernel on flat per-group streams
+  only_blocked = '--blocked' in sys.argv
+  for E in (16, 8):
+    for pad in (0, 4, 20, 68):       # rows of padding per env group (group stride = (T + pad) * E floats)
+      bsets = []
+      for s in sets:
+        planes = []
+        for x in s[:2]:
+          buf = torch.empty(N // E, T + pad, E, device=dev)
+          buf[:, :T] = F.to_blocked(x, E)
+          planes.append(buf[:, :T])
+        bsets.append((planes[0], planes[1], s[2], (torch.empty(N // E, T, E, device=dev), torch.empty(N // E, T, E, device=dev))))
+      cfgs = [(2, 0, 1), (3, 0, 1), (4, 0, 1), (3, 16, 1), (3, 32, 1), (3, 48, 1), (4, 48, 1), (3, 0, 2), (3, 48, 2)]
+      if pad == 0:
+        cfgs += [(3, 1, 1), (3, 2, 1), (3, 3, 1), (3, 9, 1), (3, 11, 1), (3, 15, 1), (3, 17, 1), (3, 49, 1)]
+      for PF, dbg, U in cfgs:
+        if E == 8 and U == 2:
+          continue
+        os.environ['TRL_GAE_TUNE'] = '0,%d,%d,%d' % (PF, dbg, U)
+        try:
+          us = graph_time_us([(lambda s=s: F.gae_blocked(s[0], s[1], s[2], 0.99, 0.95, out=s[3])) for s in bsets])
+        except Exception as e:  # noqa
+          print('blocked E=%2d pad=%d PF=%d dbg=%2d U=%d  failed: %s' % (E, pad, PF, dbg, U, str(e)[:80]))
+          continue
+        print('blocked E=%2d pad=%2d PF=%d dbg=%2d U=%d  %7.1f us %6.0f GB/s' % (E, pad, PF, dbg, U, us, algo / us / 1e3), flush=True)
+      os.environ.pop('TRL_GAE_TUNE')
+      if pad == 0:
+        nt = [(s[0], s[1], s[2], (torch.empty(N, T, device=dev), torch.empty(N, T, device=dev))) for s in bsets]
+        us = graph_time_us([(lambda s=s: F.gae_blocked(s[0], s[1], s[2], 0.99, 0.95, env_major_out=True, out=s[3])) for s in nt])
+        print('blocked E=%2d in, env-major [N, T] out (defaults)  %7.1f us %6.0f GB/s' % (E, us, algo / us / 1e3), flush=True)
+        del nt
+      del bsets
 
 
 if __name__ == '__main__':

@@ -1,5 +1,5 @@
 """In-kernel timeline of k_ac_learn from a DIAGNOSTIC build (TRL_LEARN_STAMP=1 python -m
-torchrl_amd._build --force): per wave, shader-clock and 100 MHz stamps at entry, after the weight
+torchrl_amd._build --tuning --force): per wave, shader-clock and 100 MHz stamps at entry, after the weight
 staging, after the strip loop and at the end.  Prints the medians and the in-kernel clock."""
 import os
 import sys
@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('TRL_LIB', 'tune')   # the -DTRL_TUNING diagnostic build (python -m torchrl_amd._build --tuning)
 from torchrl_amd import functional as F  # noqa: E402
 from torchrl_amd.contrib.controllers import PPOController  # noqa: E402
 

@@ -9,11 +9,14 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libtrl_hip.so')
+# tools/ select the -DTRL_TUNING diagnostic build (lib/libtrl_hip_tune.so) with TRL_LIB=tune; read once, at load
+if os.environ.get('TRL_LIB') == 'tune':
+  LIB_PATH = os.path.join(_PKG, 'lib', 'libtrl_hip_tune.so')
 
 TRL_MAX_COLS = 8
 TRL_F32, TRL_U8 = 0, 1
 TRL_GAE_REFERENCE, TRL_GAE_MASKED = 0, 1
-TRL_LAYOUT_TN, TRL_LAYOUT_NT = 0, 1
+TRL_LAYOUT_TN, TRL_LAYOUT_NT, TRL_LAYOUT_BLOCKED = 0, 1, 2
 TRL_LOSS_MSE, TRL_LOSS_HUBER = 0, 1
 
 
@@ -60,8 +63,11 @@ PROTOTYPES = {
                                    C.POINTER(_vp), C.POINTER(_i32), _vp]),
     'trl_mt19937_seed': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.c_uint64]),
     'trl_randperm_prefix': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp]),
+    'trl_randperm_prefix_direct': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp]),
     'trl_sample_indices': (C.c_int, [_i64, _i64, C.c_uint64, _vp, _vp, _vp]),
     'trl_gae_reverse_scan': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _i32, _i32, _vp, _vp, _vp]),
+    'trl_gae_reverse_scan_blocked': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _f64, _f64, _i32, _i32, _i64,
+                                               _vp, _vp, _vp]),
     'trl_loss_workspace_bytes': (_i64, []),
     'trl_td_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
     'trl_ddpg_critic_loss': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),

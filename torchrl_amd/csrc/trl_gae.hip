@@ -24,6 +24,12 @@
 // take (N % 4 != 0, unaligned bases, the masked extension).
 // HBM traffic is the algorithmic minimum: r and v read once (the v[t+1] operand re-reads the
 // same lines through L1/L2), ret and adv written once = 16 B per (t, env) step.
+//
+// Layouts.  [T, N] (env index contiguous) is what one env step over all envs appends and the parity
+// mode; there a workgroup's E = 16 envs are a 64 B segment of every row.  The BLOCKED rollout layout
+// [N / E][T][E] keeps a workgroup's E envs x T steps contiguous, so that its reward / value / returns /
+// advantage streams are flat (every LDS-DMA instruction moves 1 KiB of consecutive bytes, every tile
+// is one 4 KiB run): same kernel, the planes are addressed as base(group) + t * row_stride.
 #include <stdlib.h>
 
 #include "trl_common.h"
@@ -129,10 +135,21 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
                                                   const float *__restrict__ done,
                                                   const float *__restrict__ bootstrap, int T, int N,
                                                   float gamma, float gl, int out_nt, int ngroups,
+                                                  int64_t in_gs, int in_rs, int64_t out_gs, int out_rs,
                                                   float *__restrict__ returns,
-                                                  float *__restrict__ adv, int dbg) {
-  // dbg: ablation switches for tools/gae_sweep.py (0 in production): 1 = no chain,
-  // 2 = no output stores, 4 = no staging pass, 8 = no DMA
+                                                  float *__restrict__ adv, int dbg_in) {
+  // element (t, env) of an input plane is at  grp * in_gs + t * in_rs + (env - grp * E)  floats:
+  // [T, N]: in_gs = E, in_rs = N;  blocked [N / E][t_stride][E]: in_gs = t_stride * E, in_rs = E.
+  // The row-strided outputs (out_nt == 0) likewise with out_gs / out_rs.
+#ifdef TRL_TUNING
+  // ablation switches for tools/gae_sweep.py (diagnostic build only; results are then wrong):
+  // 1 = no chain, 2 = no output stores, 4 = no staging pass, 8 = no DMA; policy variants (results stay right):
+  // 16 = non-temporal output stores, 32 = non-temporal input loads (both set by the blocked entry point);
+  // 256 = cycle stamps of the chain wave
+  const int dbg = dbg_in;
+#else
+  const int dbg = dbg_in & 48;   // the production library honours the two cache-policy bits only
+#endif
   constexpr int QPR = E / 4;        // quads (float4) per tile row
   constexpr int RPU = 256 / QPR;    // rows covered by one pass of the 256 worker lanes
   constexpr int TT = U * RPU;       // rows per tile: U passes of the worker lanes (U = 1: half-size tiles,
@@ -174,8 +191,8 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
     // ================================================================== DMA waves
     const int dw = wave - 1;                       // owns instructions [dw*IPW, (dw+1)*IPW) of each plane
     const int q = lane % QPR, rsub = lane / QPR;
-    int envq = env0 + 4 * q;
-    envq = envq < N ? envq : 0;                    // clamped: always a valid quad
+    // clamped: a quad beyond N (ragged last group of a [T, N] rollout) reads envs 0..3 instead
+    const int64_t qoff = env0 + 4 * q < N ? (int64_t)grp * in_gs + 4 * q : 0;
     auto issue = [&](int j) {
       const int jc = j < ntiles ? j : ntiles - 1;
       const int lo = t_lo(jc), hi = t_hi(jc);
@@ -185,16 +202,28 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
         const int ins = dw * IPW + i;
         int t = lo + ins * RPI + rsub;
         t = t < hi ? t : hi - 1;
-        const int64_t g = (int64_t)t * N + envq;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reward + g),
-                                         (__attribute__((address_space(3))) void *)(slot + ins * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(value + g),
-                                         (__attribute__((address_space(3))) void *)(slot + PLANE + ins * 256), 16,
-                                         0, 0);
-        if (MASKED)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(done + g),
-                                           (__attribute__((address_space(3))) void *)(slot + 2 * PLANE + ins * 256),
-                                           16, 0, 0);
+        const int64_t g = (int64_t)t * in_rs + qoff;
+        if (dbg & 32) {   // tuning build: non-temporal policy on the input stream (aux = 2)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reward + g),
+                                           (__attribute__((address_space(3))) void *)(slot + ins * 256), 16, 0, 2);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(value + g),
+                                           (__attribute__((address_space(3))) void *)(slot + PLANE + ins * 256), 16,
+                                           0, 2);
+          if (MASKED)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(done + g),
+                                             (__attribute__((address_space(3))) void *)(slot + 2 * PLANE + ins * 256),
+                                             16, 0, 2);
+        } else {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reward + g),
+                                           (__attribute__((address_space(3))) void *)(slot + ins * 256), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(value + g),
+                                           (__attribute__((address_space(3))) void *)(slot + PLANE + ins * 256), 16,
+                                           0, 0);
+          if (MASKED)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(done + g),
+                                             (__attribute__((address_space(3))) void *)(slot + 2 * PLANE + ins * 256),
+                                             16, 0, 0);
+        }
       }
     };
     // all but the PF - 1 youngest tiles of this wave have landed
@@ -272,10 +301,15 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
                 rt[c] = __fadd_rn(sd[(4 * q + c) * TTP + tl], v);
                 ad[c] = __fsub_rn(rt[c], v);
               }
-              const int64_t g = (int64_t)(lo + tl) * N + envq;
+              const int64_t g = (int64_t)grp * out_gs + (int64_t)(lo + tl) * out_rs + 4 * q;
               const f32x4 r4 = {rt[0], rt[1], rt[2], rt[3]}, a4 = {ad[0], ad[1], ad[2], ad[3]};
-              *(f32x4 *)(returns + g) = r4;
-              if (adv) *(f32x4 *)(adv + g) = a4;
+              if (dbg & 16) {   // tuning build: non-temporal output stores
+                __builtin_nontemporal_store(r4, (f32x4 *)(returns + g));
+                if (adv) __builtin_nontemporal_store(a4, (f32x4 *)(adv + g));
+              } else {
+                *(f32x4 *)(returns + g) = r4;
+                if (adv) *(f32x4 *)(adv + g) = a4;
+              }
             }
           }
         } else {
@@ -310,15 +344,25 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
           }
         }
       }
-      __syncthreads();
+      // LDS traffic only: the output stores stay in flight across the barrier (a __syncthreads() here waits
+      // for vmcnt(0) as well, i.e. one store round trip per stage: 16 of the kernel's 30 us)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   } else {
     // ================================================================== chain wave
     float gae = 0.0f;
     __builtin_amdgcn_s_setprio(3);                   // the serial chain is the critical path: win issue arbitration
+#ifdef TRL_TUNING   // dbg & 256: cycle stamps of the chain wave (tools/gae_ablate.py); they go to adv[4 * grp ..]
+    long long st_scan = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_first = 0;
+#endif
     __syncthreads();                                 // prologue barrier
     for (int s = 0; s < nstages; ++s) {
       const int jc = s - 1;
+#ifdef TRL_TUNING
+      const long long st_a = __builtin_amdgcn_s_memtime();
+      if (s == 1) st_first = st_a;
+#endif
       if (jc >= 0 && jc < ntiles && lane < E && !(dbg & 1)) {
         const int rows = t_hi(jc) - t_lo(jc);
         float *sd = s_d + (jc % NS) * E * TTP + lane * TTP;   // this env's row of the transposed tile
@@ -416,51 +460,71 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
         }
         }   // !MASKED
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef TRL_TUNING
+      if (dbg & 256) st_scan += __builtin_amdgcn_s_memtime() - st_a;
+#endif
+      __builtin_amdgcn_s_barrier();
     }
+#ifdef TRL_TUNING
+    if ((dbg & 256) && lane == 0 && adv) {
+      const long long st_end = __builtin_amdgcn_s_memtime();
+      float *o = adv + 4 * grp;
+      o[0] = (float)st_scan;                 // cycles inside the per-tile scan sections
+      o[1] = (float)(st_end - st_t0);        // whole life of the wave after its prologue
+      o[2] = (float)(st_first - st_t0);      // until the first tile could be scanned
+      o[3] = (float)(st_end - st_first);
+    }
+#endif
   }
 }
 
+struct PipeArgs {
+  const float *reward, *value, *done, *bootstrap;
+  int T, N;
+  float gamma, gl;
+  int out_nt;
+  int64_t in_ts, out_ts;   // blocked layouts: rows allocated per env group (0: the plane is [T, N])
+  float *returns, *adv;
+  int dbg;
+};
+
 template <int E, int PF, bool MASKED, int U = 2>
-int launch_pipe(const float *reward, const float *value, const float *done, const float *bootstrap, int T, int N,
-                float gamma, float gl, int out_nt, float *returns, float *adv, int dbg, hipStream_t st) {
-  const int ngroups = (int)trl_cdiv(N, E);
-  hipLaunchKernelGGL((k_gae_pipe<E, PF, MASKED, U>), dim3(ngroups), dim3(448), 0, st, reward, value, done, bootstrap, T,
-                     N, gamma, gl, out_nt, ngroups, returns, adv, dbg);
+int launch_pipe(const PipeArgs &a, hipStream_t st) {
+  const int ngroups = (int)trl_cdiv(a.N, E);
+  const int64_t in_gs = a.in_ts ? a.in_ts * E : E, out_gs = a.out_ts ? a.out_ts * E : E;
+  const int in_rs = a.in_ts ? E : a.N, out_rs = a.out_ts ? E : a.N;
+  hipLaunchKernelGGL((k_gae_pipe<E, PF, MASKED, U>), dim3(ngroups), dim3(448), 0, st, a.reward, a.value, a.done,
+                     a.bootstrap, a.T, a.N, a.gamma, a.gl, a.out_nt, ngroups, in_gs, in_rs, out_gs, out_rs, a.returns,
+                     a.adv, a.dbg);
   TRL_CHECK_LAUNCH("trl_gae_reverse_scan");
   return TRL_OK;
 }
 
-// E and PF as run-time choices (0 = default heuristic); used by the dispatcher and the sweep tool
-int dispatch_pipe(int E, int PF, int U, const float *reward, const float *value, const float *done, const float *bootstrap,
-                  int T, int N, float gamma, float gl, int out_nt, float *returns, float *adv, int dbg,
-                  hipStream_t st) {
-  if (E == 0) E = N > 256 * 32 ? 64 : (N > 256 * 16 ? 32 : 16);
-  if (PF == 0) PF = 2;   // deeper prefetch measured no faster, cold or cache-resident (tools/gae_sweep.py)
+// E (envs per workgroup), PF (tiles in flight) and U (tile rows = U * 256 * 4 / E) as run-time choices,
+// 0 = the default heuristic.  Production calls pass zeros; the diagnostic build's sweep passes the rest.
+int dispatch_pipe(int E, int PF, int U, const PipeArgs &a, hipStream_t st) {
+  const bool masked = a.done != nullptr;
+  if (E == 0) E = a.N > 256 * 32 ? 64 : (a.N > 256 * 16 ? 32 : 16);
+  if (PF == 0) PF = 2;   // deeper prefetch measured no faster on [T, N], cold or cache-resident (tools/gae_sweep.py)
   // half-size tiles (64 rows at E = 16): twice the stages, half the pipeline fill and drain;
   // 36.6 -> 32.5 us cold at T = 2048, N = 4096
   if (U == 0) U = E == 16 ? 1 : 2;
-  if (done) {            // masked extension: three planes per ring slot, the LDS holds PF = 2 at most
-    if (E == 16 && U == 1)
-      return launch_pipe<16, 2, true, 1>(reward, value, done, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
-#define TRL_PIPE_MCASE(e)  \
-  if (E == e) return launch_pipe<e, 2, true>(reward, value, done, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
-    TRL_PIPE_MCASE(16) TRL_PIPE_MCASE(32) TRL_PIPE_MCASE(64)
-#undef TRL_PIPE_MCASE
-  }
-  if (U == 1 && E == 16) {   // half-size tiles (tools/gae_sweep.py)
-    if (PF == 2) return launch_pipe<16, 2, false, 1>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
-    if (PF == 3) return launch_pipe<16, 3, false, 1>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
-    if (PF == 4) return launch_pipe<16, 4, false, 1>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
-  }
-#define TRL_PIPE_CASE(e, pf)  \
-  if (E == e && PF == pf)     \
-    return launch_pipe<e, pf, false>(reward, value, nullptr, bootstrap, T, N, gamma, gl, out_nt, returns, adv, dbg, st);
-  TRL_PIPE_CASE(16, 2) TRL_PIPE_CASE(16, 3) TRL_PIPE_CASE(16, 4) 
-  TRL_PIPE_CASE(32, 2) TRL_PIPE_CASE(32, 3) TRL_PIPE_CASE(32, 4)
-  TRL_PIPE_CASE(64, 2) TRL_PIPE_CASE(64, 3) TRL_PIPE_CASE(64, 4)
+#define TRL_PIPE_CASE(e, pf, m, u) \
+  if (E == e && PF == pf && masked == m && U == u) return launch_pipe<e, pf, m, u>(a, st);
+  // production set
+  TRL_PIPE_CASE(16, 2, false, 1) TRL_PIPE_CASE(32, 2, false, 2) TRL_PIPE_CASE(64, 2, false, 2)
+  TRL_PIPE_CASE(16, 2, true, 1) TRL_PIPE_CASE(32, 2, true, 2) TRL_PIPE_CASE(64, 2, true, 2)
+  TRL_PIPE_CASE(16, 3, false, 1) TRL_PIPE_CASE(16, 4, false, 1)
+  TRL_PIPE_CASE(8, 2, false, 1) TRL_PIPE_CASE(8, 3, false, 1) TRL_PIPE_CASE(8, 2, true, 1)
+#ifdef TRL_TUNING
+  TRL_PIPE_CASE(16, 2, false, 2) TRL_PIPE_CASE(16, 3, false, 2) TRL_PIPE_CASE(16, 4, false, 2)
+  TRL_PIPE_CASE(16, 5, false, 1) TRL_PIPE_CASE(8, 4, false, 1)
+  TRL_PIPE_CASE(32, 3, false, 2) TRL_PIPE_CASE(32, 4, false, 2) TRL_PIPE_CASE(64, 3, false, 2) TRL_PIPE_CASE(64, 4, false, 2)
+  TRL_PIPE_CASE(16, 2, true, 2)
+#endif
 #undef TRL_PIPE_CASE
-  trl_set_error("trl_gae: unsupported tuning E=%d PF=%d", E, PF);
+  trl_set_error("trl_gae: unsupported tuning E=%d PF=%d U=%d masked=%d", E, PF, U, (int)masked);
   return TRL_EINVAL;
 }
 
@@ -479,6 +543,18 @@ int launch(bool masked, const float *reward, const float *value, const float *do
   return TRL_OK;
 }
 
+bool al16(const void *p) { return (uintptr_t)p % 16 == 0; }
+
+int check_common(const char *fn, const float *reward, const float *value, const float *done, const float *bootstrap,
+                 int64_t T, int64_t N, int32_t mode, const float *returns) {
+  TRL_REQUIRE(reward && value && bootstrap && returns, "%s: null pointer", fn);
+  TRL_REQUIRE(mode == TRL_GAE_REFERENCE || mode == TRL_GAE_MASKED, "%s: bad mode %d", fn, mode);
+  TRL_REQUIRE(mode != TRL_GAE_MASKED || done != nullptr, "%s: masked mode needs done", fn);
+  TRL_REQUIRE(T >= 0 && N >= 0 && T < (1ll << 31) && N < (1ll << 31) && T * N < (1ll << 40),
+              "%s: T=%lld N=%lld out of range", fn, (long long)T, (long long)N);
+  return TRL_OK;
+}
+
 }  // namespace
 
 extern "C" int trl_gae_reverse_scan(const float *reward, const float *value, const float *done,
@@ -488,27 +564,73 @@ extern "C" int trl_gae_reverse_scan(const float *reward, const float *value, con
   const char *fn = "trl_gae_reverse_scan";
   const float gamma = (float)gamma_d;                     // self.gamma * values[step + 1]
   const float gamma_lambda = (float)(gamma_d * lmbda_d);  // self.gamma * self.lmbda * gae
-  TRL_REQUIRE(reward && value && bootstrap && returns, "%s: null pointer", fn);
-  TRL_REQUIRE(mode == TRL_GAE_REFERENCE || mode == TRL_GAE_MASKED, "%s: bad mode %d", fn, mode);
-  TRL_REQUIRE(mode != TRL_GAE_MASKED || done != nullptr, "%s: masked mode needs done", fn);
+  int rc = check_common(fn, reward, value, done, bootstrap, T, N, mode, returns);
+  if (rc) return rc;
   TRL_REQUIRE(out_layout == TRL_LAYOUT_TN || out_layout == TRL_LAYOUT_NT, "%s: bad out_layout %d", fn,
               out_layout);
-  TRL_REQUIRE(T >= 0 && N >= 0 && T < (1ll << 31) && N < (1ll << 31) && T * N < (1ll << 40),
-              "%s: T=%lld N=%lld out of range", fn, (long long)T, (long long)N);
   if (T == 0 || N == 0) return TRL_OK;
   hipStream_t st = (hipStream_t)stream;
   const bool masked = mode == TRL_GAE_MASKED;
-  const bool aligned = N % 4 == 0 && ((uintptr_t)reward % 16 == 0) && ((uintptr_t)value % 16 == 0) &&
-                       ((uintptr_t)bootstrap % 16 == 0) && ((uintptr_t)returns % 16 == 0) &&
-                       (adv == nullptr || (uintptr_t)adv % 16 == 0);
-  if (aligned && (!masked || (uintptr_t)done % 16 == 0)) {
+  const bool aligned = N % 4 == 0 && al16(reward) && al16(value) && al16(bootstrap) && al16(returns) &&
+                       (adv == nullptr || al16(adv));
+  if (aligned && (!masked || al16(done))) {
     // Envs per workgroup: 16 (a 64 B row segment) while that gives at most one workgroup per
     // CU (the pipelined kernel holds most of a CU's LDS), then wider segments.
     int E = 0, PF = 0, dbg = 0, U = 0;
-    if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d,%d", &E, &PF, &dbg, &U);   // tools/gae_sweep.py
-    return dispatch_pipe(E, PF, U, reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma,
-                         gamma_lambda, out_layout, returns, adv, dbg, st);
+#ifdef TRL_TUNING   // diagnostic build only (tools/gae_sweep.py); the production library never reads the environment
+    if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d,%d", &E, &PF, &dbg, &U);
+#endif
+    const PipeArgs a{reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
+                     out_layout == TRL_LAYOUT_NT, 0, 0, returns, adv, dbg};
+    return dispatch_pipe(E, PF, U, a, st);
   }
   return launch<16>(masked, reward, value, done, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
                     out_layout, returns, adv, st);
+}
+
+extern "C" int trl_gae_reverse_scan_blocked(const float *reward, const float *value, const float *done,
+                                            const float *bootstrap, int64_t T, int64_t N, int32_t block_envs,
+                                            int64_t in_t_stride, double gamma_d, double lmbda_d, int32_t mode,
+                                            int32_t out_layout, int64_t out_t_stride, float *returns, float *adv,
+                                            void *stream) {
+  const char *fn = "trl_gae_reverse_scan_blocked";
+  const float gamma = (float)gamma_d;
+  const float gamma_lambda = (float)(gamma_d * lmbda_d);
+  int rc = check_common(fn, reward, value, done, bootstrap, T, N, mode, returns);
+  if (rc) return rc;
+  TRL_REQUIRE(block_envs == 8 || block_envs == 16, "%s: block_envs=%d must be 8 or 16", fn, block_envs);
+  TRL_REQUIRE(N % block_envs == 0, "%s: N=%lld must be a multiple of block_envs=%d", fn, (long long)N, block_envs);
+  TRL_REQUIRE(out_layout == TRL_LAYOUT_BLOCKED || out_layout == TRL_LAYOUT_NT, "%s: bad out_layout %d", fn, out_layout);
+  if (in_t_stride == 0) in_t_stride = T;
+  if (out_t_stride == 0) out_t_stride = T;
+  TRL_REQUIRE(in_t_stride >= T && in_t_stride < (1ll << 31), "%s: in_t_stride=%lld < T=%lld", fn,
+              (long long)in_t_stride, (long long)T);
+  TRL_REQUIRE(out_layout != TRL_LAYOUT_BLOCKED || (out_t_stride >= T && out_t_stride < (1ll << 31)),
+              "%s: out_t_stride=%lld < T=%lld", fn, (long long)out_t_stride, (long long)T);
+  TRL_REQUIRE(al16(reward) && al16(value) && al16(bootstrap) && al16(returns) && (adv == nullptr || al16(adv)) &&
+                  (mode != TRL_GAE_MASKED || al16(done)),
+              "%s: every plane must be 16-byte aligned", fn);
+  if (T == 0 || N == 0) return TRL_OK;
+  const bool masked = mode == TRL_GAE_MASKED;
+  int PF = 0, dbg = 0, U = 0;
+#ifdef TRL_TUNING
+  if (const char *tune = getenv("TRL_GAE_TUNE")) {
+    int e_ignored = 0;
+    sscanf(tune, "%d,%d,%d,%d", &e_ignored, &PF, &dbg, &U);
+  }
+#endif
+  if (U == 0) U = 1;
+  // flat per-group streams: three tiles in flight, and the non-temporal policy on the once-read inputs and the
+  // once-written outputs (tools/gae_sweep.py --blocked: 30.3 us plain -> 27.0 us, T = 2048, N = 4096, cold; on the
+  // 64 B row segments of [T, N] neither changes anything, so that path keeps PF = 2 and the default policy)
+  if (PF == 0) PF = masked ? 2 : 3;
+#ifdef TRL_TUNING
+  if (!getenv("TRL_GAE_TUNE")) dbg = 48;
+#else
+  dbg = 48;
+#endif
+  const PipeArgs a{reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
+                   out_layout == TRL_LAYOUT_NT, in_t_stride, out_layout == TRL_LAYOUT_BLOCKED ? out_t_stride : 0,
+                   returns, adv, dbg};
+  return dispatch_pipe(block_envs, PF, U, a, (hipStream_t)stream);
 }

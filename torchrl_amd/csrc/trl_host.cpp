@@ -77,6 +77,7 @@ bool jump_regen_many(uint32_t *s, int64_t r);   // O(1) in r for a full ring's s
 struct Mt {
   uint32_t *s;
   int32_t left, next;
+  bool allow_jump = true;
   void regen() {
     mt_regen(s);
     left = MT_N;
@@ -103,7 +104,7 @@ struct Mt {
     // [1, 624] draws taken from the newest state the position is left = 625 - c, next = c
     const int64_t r = (k + MT_N - 1) / MT_N;
     const int64_t c = k - (r - 1) * MT_N;
-    if (!jump_regen_many(s, r)) mt_regen_many(s, r);
+    if (!allow_jump || !jump_regen_many(s, r)) mt_regen_many(s, r);
     left = (int32_t)(MT_N + 1 - c);
     next = (int32_t)c;
   }
@@ -299,7 +300,7 @@ std::mutex g_mu;
 
 // r regenerations of s; returns false when the direct skip should be used
 bool regen_many(uint32_t *s, int64_t r) {
-  if (r < JUMP_MIN_BLOCKS || getenv("TRL_MT_NO_JUMP")) return false;
+  if (r < JUMP_MIN_BLOCKS) return false;
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_phi_ok) {
     static bool tried = false;
@@ -379,8 +380,8 @@ extern "C" int trl_mt19937_seed(uint32_t *mt, int32_t *left, int32_t *next, uint
   return TRL_OK;
 }
 
-extern "C" int trl_randperm_prefix(uint32_t *mt, int32_t *left, int32_t *next, int64_t n, int64_t B,
-                                   int64_t *out_h) {
+static int randperm_prefix_impl(uint32_t *mt, int32_t *left, int32_t *next, int64_t n, int64_t B, int64_t *out_h,
+                                bool allow_jump) {
   if (!mt || !left || !next || (B > 0 && !out_h)) {
     trl_set_error("trl_randperm_prefix: null argument");
     return TRL_EINVAL;
@@ -398,7 +399,7 @@ extern "C" int trl_randperm_prefix(uint32_t *mt, int32_t *left, int32_t *next, i
     trl_set_error("trl_randperm_prefix: corrupt generator position left=%d next=%d", *left, *next);
     return TRL_EINVAL;
   }
-  Mt g{mt, *left, *next};
+  Mt g{mt, *left, *next, allow_jump};
   const int64_t steps = n > 0 ? n - 1 : 0;  // draws torch consumes
   const int64_t live = B < steps ? B : steps;
   Sparse sp(B);
@@ -418,4 +419,14 @@ extern "C" int trl_randperm_prefix(uint32_t *mt, int32_t *left, int32_t *next, i
   *left = g.left;
   *next = g.next;
   return TRL_OK;
+}
+
+extern "C" int trl_randperm_prefix(uint32_t *mt, int32_t *left, int32_t *next, int64_t n, int64_t B,
+                                   int64_t *out_h) {
+  return randperm_prefix_impl(mt, left, next, n, B, out_h, true);
+}
+
+extern "C" int trl_randperm_prefix_direct(uint32_t *mt, int32_t *left, int32_t *next, int64_t n, int64_t B,
+                                          int64_t *out_h) {
+  return randperm_prefix_impl(mt, left, next, n, B, out_h, false);
 }

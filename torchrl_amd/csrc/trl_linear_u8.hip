@@ -272,8 +272,10 @@ bool fwd_plan(int64_t B, int32_t N, int32_t K, int P, FwdPlan *p) {
   p->kblocks = K / KB;
   const int tiles = p->mtiles * (N / FWD_NT) * P;
   int total_wgs = 512;                                 // ~2 workgroups per CU over the whole launch (flat optimum 256-768: tools/u8_fwd_sweep.py)
-  if (const char *t = getenv("TRL_U8_FWD_WGS"))        // tools: sweep of the split count
+#ifdef TRL_TUNING                                      // diagnostic build: sweep of the split count (tools/u8_fwd_sweep.py)
+  if (const char *t = getenv("TRL_U8_FWD_WGS"))
     if (atoi(t) > 0) total_wgs = atoi(t);
+#endif
   int target = (total_wgs + tiles - 1) / tiles;
   if (target < 1) target = 1;
   int bps = (p->kblocks + target - 1) / target;

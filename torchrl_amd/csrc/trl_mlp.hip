@@ -666,7 +666,9 @@ extern "C" int trl_linear_bwd(const float *dy, const float *y, const float *x, c
   const dim3 grid((unsigned)slabs, (unsigned)trl_cdiv(K, 32 * KBv)), block(256);
   TRL_REQUIRE(grid.y <= 65535, "%s: fan-in %d needs too many column chunks", fn, K);
   int dbg = 0;
-  if (const char *t = getenv("TRL_MLP_DBG")) dbg = atoi(t);   // tools/mlp_probe.py
+#ifdef TRL_TUNING   // ablation switches (wrong results, timing only): diagnostic build, tools/mlp_probe.py
+  if (const char *t = getenv("TRL_MLP_DBG")) dbg = atoi(t);
+#endif
   const bool vn = N % 4 == 0 && (uintptr_t)dy % 16 == 0 && (y == nullptr || (uintptr_t)y % 16 == 0);
   const bool vk = K % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0;
 #define TRL_BWD_LAUNCH(nb, kb, a, c)                                                                               \

@@ -10,8 +10,11 @@
 // Two gather kernels:
 //   k_gather_narrow  one lane per dword of a record region; a block takes 64 rows and
 //                    loads their 64 indices with one coalesced wave-wide load.
-//   k_gather_wide    one block per (row, 8 KiB chunk of a wide column), 16 B per lane,
-//                    or 4 B -> float4 per lane when a u8 column is cast to f32.
+//   k_gather_wide    a persistent, software-pipelined grid (4 workgroups per CU) over work items
+//                    (row, 16 KiB chunk of a wide column): 4 x 16 B non-temporal loads per lane, the
+//                    next item's loads issued before the current item's stores; 4 B -> float4 per
+//                    lane when a u8 column is cast to f32.  The record's narrow columns ride in the
+//                    same launch (its first B / 64 workgroups run the narrow body).
 // Both are pure HBM/L2 byte movers: no LDS tiling is needed because nothing is reused.
 #include <stdlib.h>
 
@@ -406,7 +409,9 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
   ColArgs na{};
   WideArgs wa{};
   int wide_un = 4;                                          // 16 KiB copy items (2: 8 KiB)
-  if (const char *t = getenv("TRL_GATHER_UN")) wide_un = atoi(t) == 2 ? 2 : 4;   // tools/gather_sweep.py
+#ifdef TRL_TUNING                                         // diagnostic build: tools/gather_sweep.py
+  if (const char *t = getenv("TRL_GATHER_UN")) wide_un = atoi(t) == 2 ? 2 : 4;
+#endif
   for (int c = 0; c < layout->ncols; ++c) {
     TRL_REQUIRE(dst[c] != nullptr, "%s: dst[%d] is null", fn, c);
     const int od = out_dtype[c];
@@ -458,8 +463,10 @@ int gather_impl(const char *fn, bool range, const void *ring, int64_t capacity, 
     // persistent grid of 4 workgroups per CU over 16 KiB items (measured best on MI355X among 1-32 per CU
     // and 8 / 16 KiB items: tools/gather_sweep.py); a small batch is one item per workgroup
     int64_t cap_blocks = 1024;
-    if (const char *t = getenv("TRL_GATHER_WG_PER_CU"))      // tools/gather_sweep.py
+#ifdef TRL_TUNING                                         // diagnostic build: tools/gather_sweep.py
+    if (const char *t = getenv("TRL_GATHER_WG_PER_CU"))
       if (atoi(t) > 0) cap_blocks = (int64_t)256 * atoi(t);
+#endif
     const unsigned grid = (unsigned)(items < cap_blocks ? items : cap_blocks) + narrow_blocks;
 #define TRL_WIDE_LAUNCH(R, U)                                                                               \
   hipLaunchKernelGGL((k_gather_wide<R, U>), dim3(grid), dim3(256), 0, st, (const char *)ring, capacity, stride, \

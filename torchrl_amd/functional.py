@@ -72,6 +72,83 @@ def gae(reward, value, bootstrap, gamma, lmbda, done=None, masked=False, env_maj
   return returns, adv
 
 
+def _blocked_plane(t, what):
+  """A [G, T, E] float32 device plane whose env groups are contiguous [T, E] runs: strides
+  (t_stride * E, E, 1) with t_stride >= T (a [:, :T] slice of a [G, capacity, E] buffer qualifies).
+  Returns t_stride."""
+  _lib.require_device(t, what)
+  if t.dtype != torch.float32 or t.dim() != 3:
+    raise TypeError('%s must be a float32 [N / E, T, E] tensor, got %s %s' % (what, t.dtype, tuple(t.shape)))
+  G, T, E = t.shape
+  if E not in (8, 16):
+    raise ValueError('%s: the blocked layout holds 8 or 16 envs per group, got %d' % (what, E))
+  if G * T == 0:
+    return T
+  # (the stride of a size-1 dimension is arbitrary in torch)
+  if t.stride(2) != 1 or (T > 1 and t.stride(1) != E) or (G > 1 and (t.stride(0) % E or t.stride(0) < T * E)):
+    raise ValueError('%s: expected strides (t_stride * E, E, 1), got %s' % (what, t.stride()))
+  return t.stride(0) // E if G > 1 else T
+
+
+def gae_blocked(reward, value, bootstrap, gamma, lmbda, done=None, masked=False, env_major_out=False,
+                want_adv=True, out=None):
+  """`gae` over a rollout kept in the blocked layout (C ABI trl_gae_reverse_scan_blocked).
+
+  reward, value (and done when masked): [N / E, T, E] float32, E = 8 or 16 consecutive envs per group,
+  group g's [T, E] run contiguous (RolloutBuffer(layout='blocked').tensors(), or the value kernel's
+  output over blocked observations); bootstrap: [N].  Same arithmetic and bit-identical results as
+  `gae` on the [T, N] transposition.  Returns (returns, adv): [N / E, T, E], or env-major [N, T] with
+  env_major_out."""
+  ts = _blocked_plane(reward, 'reward')
+  if value.shape != reward.shape or _blocked_plane(value, 'value') != ts:
+    raise ValueError('gae_blocked: value must have reward\'s shape and strides')
+  G, T, E = reward.shape
+  N = G * E
+  bootstrap = _f32c(bootstrap, 'bootstrap')
+  if bootstrap.numel() != N:
+    raise ValueError('gae_blocked: bootstrap must be [%d]' % N)
+  if masked:
+    if done is None:
+      raise ValueError('masked GAE needs done')
+    if done.shape != reward.shape or _blocked_plane(done, 'done') != ts:
+      raise ValueError('gae_blocked: done must have reward\'s shape and strides')
+  shape = (N, T) if env_major_out else (G, T, E)
+  if out is not None:
+    returns, adv = out
+    for o in (returns, adv):
+      if o is not None and (o.shape != shape or o.dtype != torch.float32 or not o.is_contiguous()
+                            or o.device != reward.device):
+        raise ValueError('gae_blocked: out tensors must be contiguous float32 %s on %s' % (shape, reward.device))
+  else:
+    returns = torch.empty(shape, dtype=torch.float32, device=reward.device)
+    adv = torch.empty(shape, dtype=torch.float32, device=reward.device) if want_adv else None
+  with torch.cuda.device(reward.device):
+    _lib.check(_lib.lib().trl_gae_reverse_scan_blocked(
+        reward.data_ptr(), value.data_ptr(), _lib.ptr(done) if masked else None, bootstrap.data_ptr(),
+        T, N, E, ts, float(gamma), float(lmbda), TRL_GAE_MASKED if masked else TRL_GAE_REFERENCE,
+        TRL_LAYOUT_NT if env_major_out else _lib.TRL_LAYOUT_BLOCKED, 0, returns.data_ptr(), _lib.ptr(adv),
+        _lib.stream_ptr(reward.device)))
+  return returns, adv
+
+
+def to_blocked(x, block_envs=16):
+  """[T, N, ...] -> the blocked layout [N / E, T, E, ...] (a copy)."""
+  T, N = x.shape[:2]
+  if N % block_envs:
+    raise ValueError('N=%d is not a multiple of block_envs=%d' % (N, block_envs))
+  rest = tuple(x.shape[2:])
+  perm = (1, 0, 2) + tuple(range(3, 3 + len(rest)))
+  return x.reshape((T, N // block_envs, block_envs) + rest).permute(perm).contiguous()
+
+
+def from_blocked(x):
+  """[N / E, T, E, ...] -> [T, N, ...] (a copy)."""
+  G, T, E = x.shape[:3]
+  rest = tuple(x.shape[3:])
+  perm = (1, 0, 2) + tuple(range(3, 3 + len(rest)))
+  return x.permute(perm).reshape((T, G * E) + rest).contiguous()
+
+
 # ------------------------------------------------------------------------------ TD losses
 class _TdLoss(torch.autograd.Function):
   @staticmethod

@@ -36,11 +36,12 @@ class Mt19937Sampler:
     _lib.check(_lib.lib().trl_mt19937_seed(self._mt.ctypes.data, C.byref(self._left),
                                            C.byref(self._next), C.c_uint64(int(seed) & (2 ** 64 - 1))))
 
-  def randperm_prefix(self, n, batch_size):
+  def randperm_prefix(self, n, batch_size, jump=True):
+    """jump=False: the block-by-block skip only (trl_randperm_prefix_direct); same indices and state."""
     out = np.empty(int(batch_size), dtype=np.int64)
-    _lib.check(_lib.lib().trl_randperm_prefix(self._mt.ctypes.data, C.byref(self._left),
-                                              C.byref(self._next), int(n), int(batch_size),
-                                              out.ctypes.data))
+    fn = _lib.lib().trl_randperm_prefix if jump else _lib.lib().trl_randperm_prefix_direct
+    _lib.check(fn(self._mt.ctypes.data, C.byref(self._left), C.byref(self._next), int(n), int(batch_size),
+                  out.ctypes.data))
     return torch.from_numpy(out)
 
 
