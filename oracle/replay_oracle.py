@@ -30,7 +30,10 @@ class FifoColumns:
       new = np.asarray(new)
       if self.cols[i] is None:
         self.cols[i] = np.zeros((0,) + new.shape[1:], dtype=np.float32)
-      self.cols[i] = truncated_cat(self.cols[i], new.astype(np.float32), self.size)
+      # torch.cat's promotion of the float32 column with the pushed dtype (:35, :10): float64 wins (the
+      # whole column becomes float64), every integer / bool / half dtype gives float32
+      dt = np.float64 if np.float64 in (new.dtype, self.cols[i].dtype) else np.float32
+      self.cols[i] = truncated_cat(self.cols[i].astype(dt), new.astype(dt), self.size)
 
   def extend_transitions(self, transitions):
     if len(transitions) == 0:

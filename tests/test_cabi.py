@@ -111,3 +111,23 @@ def test_sampler_jump_ahead_equals_direct_skip_and_torch():
   for x, y in zip(exp, got):
     assert torch.equal(x, y)
   assert torch.equal(after, torch.randint(0, 2 ** 31, (4,)))
+
+
+def test_production_library_has_no_environment_switches():
+  """The shipped library reads no environment variable: the tuning / ablation switches of tools/*_sweep.py
+  (TRL_GAE_TUNE's ablation bits give wrong results by design) exist only in the -DTRL_TUNING diagnostic
+  build, lib/libtrl_hip_tune.so."""
+  blob = open(_lib.LIB_PATH, 'rb').read()
+  for knob in (b'TRL_GAE_TUNE', b'TRL_MLP_DBG', b'TRL_GATHER_UN', b'TRL_GATHER_WG_PER_CU', b'TRL_U8_FWD_WGS',
+               b'TRL_MT_NO_JUMP'):
+    assert knob not in blob, knob
+  handle = C.CDLL(_lib.LIB_PATH)
+  assert not hasattr(handle, 'getenv') or True   # (libc's symbol resolves through any handle; the strings are the check)
+  # a stray variable changes nothing an argument check can see: same validation path, same error text
+  os.environ['TRL_GAE_TUNE'] = '64,9,15,7'
+  try:
+    lib = _lib.lib()
+    rc = lib.trl_gae_reverse_scan(None, None, None, None, 4, 4, 0.99, 0.95, 0, 0, None, None, None)
+    assert rc == -1 and b'null pointer' in lib.trl_last_error()
+  finally:
+    del os.environ['TRL_GAE_TUNE']

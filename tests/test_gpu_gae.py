@@ -274,6 +274,21 @@ def test_blocked_bad_arguments_raise():
                   0.99, 0.95)                                               # 12 envs per group
 
 
+def test_production_library_ignores_tuning_environment(monkeypatch):
+  """TRL_GAE_TUNE drives the diagnostic build's ablation switches (no chain, no stores: wrong results by design);
+  the shipped library must not react to it."""
+  monkeypatch.setenv('TRL_GAE_TUNE', '16,2,15,1')
+  T, N = 130, 64
+  rs = np.random.RandomState(2)
+  reward, value, boot = rs.randn(T, N).astype(np.float32), rs.randn(T, N).astype(np.float32), rs.randn(N).astype(np.float32)
+  exp_r, exp_a = gae_oracle.gae_numpy(reward, value, boot, 0.99, 0.95)
+  got_r, got_a = _run(reward, value, boot, 0.99, 0.95)
+  np.testing.assert_array_equal(got_r, exp_r)
+  np.testing.assert_array_equal(got_a, exp_a)
+  r, a = _run_blocked(reward, value, boot, 0.99, 0.95, 16)
+  np.testing.assert_array_equal(F.from_blocked(r).cpu().numpy(), exp_r)
+
+
 def test_bad_arguments_raise():
   x = torch.zeros(4, 4, device=DEV)
   with pytest.raises(ValueError):

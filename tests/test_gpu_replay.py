@@ -172,10 +172,86 @@ def test_errors_are_loud():
     ds[3]
   with pytest.raises(IndexError):
     ds[torch.tensor([0, 5])]
+  with pytest.raises(TypeError):        # float64 into an existing float32 column (the one promotion not reproduced)
+    f32 = TensorTupleDataset(device=DEV)
+    f32.extend(torch.zeros(2, 2))
+    f32.extend(torch.zeros(2, 2, dtype=torch.float64))
   with pytest.raises(TypeError):
-    TensorTupleDataset(device=DEV).extend(torch.zeros(2, 2, dtype=torch.float64))
+    TensorTupleDataset(device=DEV).extend(torch.zeros(2, 2, dtype=torch.complex64))
   with pytest.raises(Exception):
     TensorTupleDataset(device='cpu').extend(torch.zeros(2, 2))
+
+
+def test_dtype_promotion_golden(golden):
+  """storage.py:35 + torch.cat promotion: a float64 column stays float64, int64 becomes float32 (the
+  reference's own outputs, tests/golden/storage.npz tt_a / tt_b: size 4, six rows pushed)."""
+  g = golden('storage.npz')
+  ds = TensorTupleDataset(size=4, device=DEV)
+  ds.extend(torch.arange(12, dtype=torch.float64).reshape(6, 2), torch.arange(6, dtype=torch.int64).reshape(6, 1))
+  a, b = ds[:]
+  assert a.dtype == torch.float64 and b.dtype == torch.float32 and len(ds) == 4
+  np.testing.assert_array_equal(a.cpu().numpy(), g['tt_a'])
+  np.testing.assert_array_equal(b.cpu().numpy(), g['tt_b'])
+  assert g['tt_a'].dtype == np.float64
+  # wrapping pushes of a float64 column (values no float32 holds), from the host and from the device
+  ref = replay_oracle.FifoColumns(size=7)
+  ds = TensorTupleDataset(size=7, device=DEV)
+  rs = np.random.RandomState(1)
+  for pi, k in enumerate([3, 5, 2, 9, 1]):
+    x, y = rs.randn(k, 3) + 1e-12, rs.randn(k, 1).astype(np.float32)
+    ds.extend(torch.from_numpy(x).to(DEV) if pi % 2 else torch.from_numpy(x), torch.from_numpy(y))
+    ref.extend(x, y)
+    got = ds[:]
+    assert got[0].dtype == torch.float64
+    for gt, ex in zip(_cpu(got), ref[slice(None)]):
+      np.testing.assert_array_equal(gt, ex)
+    idx = rs.randint(0, len(ds), size=11).astype(np.int64)
+    for gt, ex in zip(_cpu(ds[torch.from_numpy(idx)]), ref[idx]):
+      np.testing.assert_array_equal(gt, ex)
+
+
+def test_dataloader_contract_one_gather_per_minibatch(monkeypatch):
+  """examples/ppo.py:66-73: `DataLoader(TensorTupleDataset(x=[8 columns]), batch_size)` -- sequential,
+  un-shuffled, last partial batch kept.  Same minibatches as iter_batches(), one gather launch each
+  (torch's batched-fetch hook __getitems__), not one per row; shuffled loaders take the index gather."""
+  from torch.utils.data import DataLoader
+  from torchrl_amd import _lib
+  n, B = 1000, 64
+  g = torch.Generator(device=DEV).manual_seed(3)
+  cols = [torch.randn(n, w, device=DEV, generator=g) for w in (3, 1, 1, 3, 1, 1, 1, 1)]   # obs .. advantages
+  ds = TensorTupleDataset(x=cols)
+  assert len(ds) == n and ds.device.type == 'cuda'
+  lib = _lib.lib()
+  calls = {'range': 0, 'rows': 0}
+  real_range, real_rows = lib.trl_gather_range, lib.trl_gather_rows
+
+  def count_range(*a):
+    calls['range'] += 1
+    return real_range(*a)
+
+  def count_rows(*a):
+    calls['rows'] += 1
+    return real_rows(*a)
+  monkeypatch.setattr(lib, 'trl_gather_range', count_range)
+  monkeypatch.setattr(lib, 'trl_gather_rows', count_rows)
+  batches = list(DataLoader(ds, batch_size=B))
+  nb = (n + B - 1) // B
+  assert len(batches) == nb and calls == {'range': nb, 'rows': 0}
+  for bi, (mb, ref) in enumerate(zip(batches, ds.iter_batches(B))):
+    lo, hi = bi * B, min(n, (bi + 1) * B)
+    assert len(mb) == 8
+    for c, (got, exp) in enumerate(zip(mb, ref)):
+      assert got.is_cuda and got.shape == (hi - lo, cols[c].shape[1])
+      assert torch.equal(got, exp) and torch.equal(got, cols[c][lo:hi])
+  # a shuffling sampler: one index gather per minibatch, rows as the sampler drew them
+  calls.update(range=0, rows=0)
+  order = torch.randperm(n, generator=torch.Generator().manual_seed(0)).tolist()
+  shuffled = list(DataLoader(ds, batch_size=B, sampler=order))       # any order a sampler draws
+  assert calls == {'range': 0, 'rows': nb}
+  got0 = torch.cat([mb[0] for mb in shuffled])
+  assert torch.equal(got0, cols[0][torch.tensor(order, device=DEV)])
+  # single rows still work (test_storage.py:25 indexes with an int)
+  assert torch.equal(ds[5][0], cols[0][5])
 
 
 def test_large_ring_properties():

@@ -37,6 +37,13 @@ def test_replay_oracle_matches_reference(golden):
   ds = replay_oracle.FifoColumns(size=3)
   ds.extend_transitions([])
   assert len(ds) == int(g['empty_len']) == 0
+  # dtype promotion of generic columns (storage.py:35 + torch.cat): float64 stays float64, int64 -> float32
+  tt = replay_oracle.FifoColumns(size=4)
+  tt.extend(np.arange(12, dtype=np.float64).reshape(6, 2), np.arange(6, dtype=np.int64).reshape(6, 1))
+  a, b = tt[slice(None)]
+  assert a.dtype == g['tt_a'].dtype == np.float64 and b.dtype == g['tt_b'].dtype == np.float32
+  np.testing.assert_array_equal(a, g['tt_a'])
+  np.testing.assert_array_equal(b, g['tt_b'])
 
 
 def test_sampler_oracle_matches_torch_randperm(golden):

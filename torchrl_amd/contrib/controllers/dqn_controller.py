@@ -46,10 +46,13 @@ class DQNController(Controller):
     # fused backward; the reference's 128-wide QNet goes through autograd, where fresh gradient
     # tensors + one multi-tensor copy replace a fill and six accumulate launches per step
     fusable = _fusable_stack(list(self.q_net.net)) is not None
-    self._q = FlatParams(self.q_net, fresh_grads=not fusable)
+    self._sync = GradSync(process_group)
+    # (not under graph replay with a gradient exchange: the replayed backward writes into the capture's own
+    # gradient tensors, which collect_grads() outside the graph never sees again -- there the gradients
+    # accumulate into the flat views, as in the PPO / A2C controllers)
+    self._q = FlatParams(self.q_net, fresh_grads=not fusable and not (graph and self._sync.enabled))
     self._target = FlatParams(self.target_q_net)
     self._target.copy_from(self._q)            # target_q_net.load_state_dict(q_net.state_dict())
-    self._sync = GradSync(process_group)
     self._sync.broadcast_params(self._q, self._target)
     self.q_net_optim = FlatAdam(self._q, lr=lr, grad_scale=self._sync.scale, device_state=graph)
     if fusable:     # one use per backward, zeroed grads: let the fused backward write .grad itself

@@ -355,17 +355,39 @@ def polyak_(target, source, tau):
 
 
 # ------------------------------------------------------------------------------ MLP layers
+class _Workspace:
+  """Device scratch grown on demand.  A buffer that has been handed out is NEVER released: its address
+  may be baked into a captured HIP graph (GraphedStep), whose later replays would otherwise write their
+  partial sums into memory the caching allocator has given to someone else.  Superseded buffers are
+  kept alive in `retired` (sizes grow geometrically, so the total stays under twice the largest)."""
+
+  def __init__(self, min_bytes=1 << 20):
+    self.min_bytes = min_bytes
+    self.buf = None
+    self.retired = []
+
+  def get(self, device, nbytes):
+    if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+      if self.buf is not None:
+        self.retired.append(self.buf)
+        nbytes = max(nbytes, 2 * self.buf.numel())
+      self.buf = torch.empty(max(nbytes, self.min_bytes), dtype=torch.uint8, device=device)
+    return self.buf
+
+
 _lin_ws = {}
 
 
 def _linear_ws(device, nbytes):
-  """Per-device scratch for the weight-gradient partials, grown on demand."""
+  """Per-device scratch of the layer-by-layer autograd Functions (weight-gradient partials).  Shared by
+  every such call on the device: the kernels of one call finish with it before the next call's start
+  (same stream); callers that run these Functions on several streams at once need one process each.
+  The whole-step objects (FusedPpoLearn, FusedDdpgLearn, FusedDqnLearn) own their workspaces instead."""
   key = device.index if device.index is not None else torch.cuda.current_device()
   ws = _lin_ws.get(key)
-  if ws is None or ws.numel() < nbytes:
-    ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-    _lin_ws[key] = ws
-  return ws
+  if ws is None:
+    ws = _lin_ws[key] = _Workspace()
+  return ws.get(device, nbytes)
 
 
 class _LinearAct(torch.autograd.Function):
@@ -629,6 +651,7 @@ class FusedPpoLearn:
     self.K0 = critic_lin[0].in_features
     self.device = critic_lin[0].weight.device
     self._key = None
+    self._ws = _Workspace()      # this object's own scratch (its address may be captured into a HIP graph)
     self._bind()
 
   def _ptr_key(self):
@@ -696,7 +719,7 @@ class FusedPpoLearn:
       self._bind()
     dev = obs.device
     lib = _lib.lib()
-    ws = _linear_ws(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
+    ws = self._ws.get(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
     losses = torch.empty(4, dtype=torch.float32, device=dev)
     aref = None
     if adam is not None:
@@ -724,7 +747,7 @@ class FusedPpoLearn:
     adv = returns.view(-1) - value
     dev = obs.device
     lib = _lib.lib()
-    ws = _linear_ws(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
+    ws = self._ws.get(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
     losses = torch.empty(4, dtype=torch.float32, device=dev)
     aref = C.byref(adam.fused_args()) if adam is not None else None
     with torch.cuda.device(dev):
@@ -801,6 +824,7 @@ class FusedDdpgLearn(_FusedOffPolicy):
     for i, lin in enumerate(self.lins):
       self._desc(self.descs, i, lin)
     self._key = self._ptr_key()
+    self._ws = _Workspace()
 
   def _ptr_key(self):
     return tuple(l[0].weight.data_ptr() for l in self.lins) + tuple(f.data.data_ptr() for f in self.flats)
@@ -821,7 +845,7 @@ class FusedDdpgLearn(_FusedOffPolicy):
     dev = obs.device
     lib = _lib.lib()
     d = self.descs
-    ws = _linear_ws(dev, lib.trl_ddpg_learn_workspace_bytes(C.byref(d[0]), C.byref(d[1]), B))
+    ws = self._ws.get(dev, lib.trl_ddpg_learn_workspace_bytes(C.byref(d[0]), C.byref(d[1]), B))
     losses = torch.empty(2, dtype=torch.float32, device=dev)
     a_args, c_args = actor_optim.fused_args(update, True), critic_optim.fused_args(update, True)
     kind, delta = (0, 0.0) if huber_delta is None else (1, float(huber_delta))
@@ -879,6 +903,7 @@ class FusedDqnLearn(_FusedOffPolicy):
     for i, lin in enumerate(self.lins):
       self._desc(self.descs, i, lin)
     self._key = self._ptr_key()
+    self._ws = _Workspace()
 
   def _ptr_key(self):
     return tuple(l[0].weight.data_ptr() for l in self.lins) + tuple(f.data.data_ptr() for f in self.flats)
@@ -902,7 +927,7 @@ class FusedDqnLearn(_FusedOffPolicy):
     dev = obs.device
     lib = _lib.lib()
     d = self.descs
-    ws = _linear_ws(dev, (lib.trl_dqn_learn_u8_workspace_bytes if u8 else lib.trl_dqn_learn_workspace_bytes)(
+    ws = self._ws.get(dev, (lib.trl_dqn_learn_u8_workspace_bytes if u8 else lib.trl_dqn_learn_workspace_bytes)(
         C.byref(d[0]), B))
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     args = optim.fused_args(update, True)

@@ -11,8 +11,10 @@ Differences a caller can observe (all additive):
   * rows live on a HIP device; results come back on that device (`.to(device)` in
     examples/dqn.py:41 is then a no-op).  There is no CPU storage path.
   * columns are stored as float32 (what `torch.Tensor(b)` yields at storage.py:65-67), or,
-    opt-in, as uint8 with an exact cast back to float32 at gather time.  A float64 column,
-    which the reference would keep as float64 through `torch.cat` promotion, is refused.
+    opt-in, as uint8 with an exact cast back to float32 at gather time.  A column first pushed
+    as float64 is kept float64, as `torch.cat` promotion does in the reference (storage.py:35 +
+    :10); the one promotion not reproduced is a float64 push into a column that already holds
+    float32 rows (the reference re-types the whole column then; here that push raises).
   * `sample(batch_size)` = `self[torch.randperm(len(self))[:batch_size]]` with the same
     indices and the same effect on torch's CPU generator, without the O(n) permutation.
 """
@@ -32,7 +34,8 @@ Transition = namedtuple('Transition', ['obs', 'action', 'reward', 'next_obs', 'd
 
 _WIDE_BYTES = 1024        # must match WIDE_MIN_BYTES in csrc/trl_replay.hip
 _MIN_UNBOUNDED_ROWS = 1024
-_F32_PROMOTABLE = (torch.float32, torch.float16, torch.bfloat16, torch.uint8, torch.int8,
+_ITEMSIZE = {torch.uint8: 1, torch.float32: 4, torch.float64: 8}
+_F32_PROMOTABLE = (torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.uint8, torch.int8,
                    torch.int16, torch.int32, torch.int64, torch.bool)
 
 
@@ -52,7 +55,7 @@ class _Layout:
     self.feat_shapes = [tuple(s) for s in feat_shapes]
     self.storage_dtypes = list(storage_dtypes)
     self.widths = [int(np.prod(s, dtype=np.int64)) if len(s) else 1 for s in self.feat_shapes]
-    self.col_bytes = [w * (1 if d == torch.uint8 else 4) for w, d in zip(self.widths, self.storage_dtypes)]
+    self.col_bytes = [w * _ITEMSIZE[d] for w, d in zip(self.widths, self.storage_dtypes)]
     off, offs, wide = 0, [], False
     for nbytes in self.col_bytes:
       is_wide = nbytes >= _WIDE_BYTES and nbytes % 16 == 0
@@ -70,6 +73,7 @@ class _Layout:
     for i, (o, b, d) in enumerate(zip(offs, self.col_bytes, self.storage_dtypes)):
       self.c.col_off[i] = o
       self.c.col_bytes[i] = b
+      # (a float64 column is 2 raw dwords per element to the byte-moving kernels: TRL_F32 = "no cast")
       self.c.col_dtype[i] = _lib.TRL_U8 if d == torch.uint8 else _lib.TRL_F32
 
   def same_as(self, other):
@@ -136,12 +140,23 @@ class TensorTupleDataset(Dataset):
       raise _lib.TrlError('torchrl_amd replay storage lives on a HIP device, not %s' % self._device)
 
   def _make_layout(self, tensors):
-    sd = self._storage_dtypes or [torch.float32] * len(tensors)
+    if self._storage_dtypes is not None:
+      sd = self._storage_dtypes
+    elif self._layout is not None and self._count > 0:
+      sd = self._layout.storage_dtypes        # a column keeps the dtype it was created with
+    else:
+      # zeros(0, ...) float32 cat the pushed tensor (storage.py:35, :10): float64 stays float64,
+      # everything else torch.cat promotes to float32
+      sd = [torch.float64 if t.dtype == torch.float64 else torch.float32 for t in tensors]
     if len(sd) != len(tensors):
       raise ValueError('storage_dtypes has %d entries for %d columns' % (len(sd), len(tensors)))
-    for d in sd:
-      if d not in (torch.float32, torch.uint8):
-        raise TypeError('columns are stored as float32 or uint8, not %s' % d)
+    for d, t in zip(sd, tensors):
+      if d not in (torch.float32, torch.uint8, torch.float64):
+        raise TypeError('columns are stored as float32, float64 or uint8, not %s' % d)
+      if t.dtype == torch.float64 and d != torch.float64:
+        raise TypeError('a float64 push into a %s column: the reference would re-type the whole column to '
+                        'float64 here (torch.cat promotion); torchrl_amd keeps a column\'s dtype -- push '
+                        'float64 from the start or cast the rows' % d)
     return _Layout([t.shape[1:] for t in tensors], sd)
 
   def _allocate(self, rows):
@@ -176,8 +191,7 @@ class TensorTupleDataset(Dataset):
       if t.dim() < 1 or t.shape[0] != k:
         raise ValueError('every column must be [k, ...] with the same k')
       if t.dtype not in _F32_PROMOTABLE:
-        raise TypeError('column dtype %s would not be float32 in the reference either; '
-                        'torchrl_amd stores float32/uint8 only' % t.dtype)
+        raise TypeError('column dtype %s is not one torchrl_amd stores (float32 / float64 / uint8 columns)' % t.dtype)
     self._bind(tensors)
     layout = self._make_layout(tensors)
     if self._layout is None or self._count == 0:
@@ -294,9 +308,10 @@ class TensorTupleDataset(Dataset):
 
   # ------------------------------------------------------------------ gather
   def _out_dtypes(self):
-    gd = self._gather_dtypes or [torch.float32] * self._layout.ncols
-    for g, s in zip(gd, self._layout.storage_dtypes):
-      if g != torch.float32 and g != s:
+    sd = self._layout.storage_dtypes
+    gd = self._gather_dtypes or [torch.float64 if s == torch.float64 else torch.float32 for s in sd]
+    for g, s in zip(gd, sd):
+      if g != s and not (g == torch.float32 and s == torch.uint8):
         raise TypeError('cannot gather a %s column as %s' % (s, g))
     return gd
 
@@ -339,6 +354,12 @@ class TensorTupleDataset(Dataset):
     pinned staging buffers; a slot is reused only after the gather that read it has finished."""
     n = index.numel()
     if self._pin is None or self._pin[0][0].numel() < n:
+      if self._pin is not None:
+        # a queued gather may still be reading its indices out of the old pinned buffers (zero-copy):
+        # wait for every slot that was ever used before the buffers go back to the host allocator
+        for (_, ev), used in zip(self._pin, self._pin_used):
+          if used:
+            ev.synchronize()
       cap = max(4096, 1 << (max(n, 1) - 1).bit_length())
       self._pin = [(torch.empty(cap, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(4)]
       self._pin_next = 0
@@ -361,6 +382,23 @@ class TensorTupleDataset(Dataset):
     ev.record(torch.cuda.current_stream(self._device))
     self._pin_used[slot] = True
     return outs
+
+  def __getitems__(self, indices):
+    """torch's batched-fetch hook (torch.utils.data's fetcher calls it with a minibatch's list of row
+    numbers when it exists): a `DataLoader(ds, batch_size)` minibatch (examples/ppo.py:66-73) is ONE
+    gather launch -- a range gather for the sequential sampler's consecutive rows -- instead of one
+    launch per row.  Returns the per-row samples the default collate expects; they are views of the
+    one gathered batch, so collation is a single stack per column."""
+    idx = [int(i) for i in indices]
+    n = self._count
+    if not idx:
+      return []
+    if idx[-1] - idx[0] == len(idx) - 1 and idx[0] >= 0 and idx[-1] < n and \
+        all(b - a == 1 for a, b in zip(idx, idx[1:])):
+      cols = self._gather_range(idx[0], len(idx))
+    else:
+      cols = self[torch.tensor(idx, dtype=torch.int64)]
+    return [[c[r] for c in cols] for r in range(len(idx))]
 
   def __getitem__(self, index) -> List[torch.Tensor]:
     if self._layout is None or self._count == 0:
