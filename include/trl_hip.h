@@ -413,6 +413,23 @@ int trl_dqn_learn_fused_u8(const trl_mlp_desc *q_net, const trl_mlp_desc *target
                            int64_t B, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
                            float *loss_out, const trl_adam_args *opt, void *ws, void *stream);
 
+/* ------------------------------------------------------------------ no-allocation entry point
+ * trl_ppo_loss for callers that cannot allocate or bring a workspace: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which has no device code at
+ * all); it is the same computation, kernels and results as trl_ppo_loss above, with the reduction scratch (the
+ * per-block partial sums of one launch) in a file-scope device array of the library instead of the `ws` argument:
+ * 1024 x (4 + 64) floats = 272 KiB per GPU, held by every GPU the library runs on until the process ends.
+ *   Limits: 1 <= A <= 64, 1 <= B <= TRL_PPO_LOSS_STATIC_MAX_B; anything else is refused with TRL_EINVAL before
+ *   anything is enqueued.  The call allocates nothing and synchronises nothing; the first call on a device looks the
+ *   array's device address up (hipGetSymbolAddress), later calls reuse it.
+ *   Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ *   calls on one stream are ordered and safe.  Nothing in the array has to be cleared between calls. */
+#define TRL_PPO_LOSS_STATIC_MAX_B (1ll << 30)
+int trl_ppo_loss_static(const float *mean, const float *log_std, const float *value, const float *action,
+                        const float *old_logp, const float *adv, const float *returns, int64_t B, int32_t A,
+                        double clip, double alpha, double beta, float *losses_out, float *dmean, float *dlog_std,
+                        float *dvalue, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

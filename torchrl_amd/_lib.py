@@ -73,6 +73,8 @@ PROTOTYPES = {
     'trl_ddpg_critic_loss': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
     'trl_ppo_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64,
                                _vp, _vp, _vp, _vp, _vp, _vp]),
+    'trl_ppo_loss_static': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64,
+                                      _vp, _vp, _vp, _vp, _vp]),
     'trl_normal_logp': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'trl_a2c_loss': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _vp]),
     'trl_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _i64, _f64, _f64, _vp]),

@@ -13,6 +13,8 @@
 // finished in the same launch.
 #include <math.h>
 
+#include <mutex>
+
 #include "trl_common.h"
 
 namespace {
@@ -424,12 +426,11 @@ extern "C" int trl_ddpg_critic_loss(const float *cur_q, const float *next_q, con
   return TRL_OK;
 }
 
-extern "C" int trl_ppo_loss(const float *mean, const float *log_std, const float *value,
-                            const float *action, const float *old_logp, const float *adv,
-                            const float *returns, int64_t B, int32_t A, double clip, double alpha,
-                            double beta, float *losses_out, float *dmean, float *dlog_std, float *dvalue,
-                            void *ws, void *stream) {
-  const char *fn = "trl_ppo_loss";
+namespace {
+int ppo_loss_impl(const char *fn, const float *mean, const float *log_std, const float *value, const float *action,
+                  const float *old_logp, const float *adv, const float *returns, int64_t B, int32_t A, double clip,
+                  double alpha, double beta, float *losses_out, float *dmean, float *dlog_std, float *dvalue, void *ws,
+                  void *stream) {
   TRL_REQUIRE(mean && log_std && value && action && old_logp && adv && returns && losses_out && ws,
               "%s: null pointer", fn);
   TRL_REQUIRE(B > 0 && A > 0 && A <= MAX_PPO_A && B * A < (1ll << 40), "%s: B=%lld A=%d out of range (A <= %d)",
@@ -453,6 +454,65 @@ extern "C" int trl_ppo_loss(const float *mean, const float *log_std, const float
     TRL_CHECK_LAUNCH(fn);
   }
   return TRL_OK;
+}
+
+// ---- scratch of the no-allocation entry point: the per-block partial sums of ONE loss launch (any batch size: the
+// grid is capped at MAX_BLOCKS), WS_FLOATS * 4 = 272 KiB per device, held by every GPU the library runs on until the
+// process ends.  In host code the array's name is only a handle: the device address comes from
+// hipGetSymbolAddress, once per device with that device current, and is what the kernels are given.
+static __device__ __align__(256) float g_static_scratch[WS_FLOATS];
+constexpr int MAX_DEVICES = 64;
+float *g_static_scratch_ptr[MAX_DEVICES];      // per device: each GPU holds its own copy at its own address
+std::mutex g_static_scratch_mu;
+
+int static_scratch(const char *fn, float **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+    trl_set_error("%s: hipGetDevice failed or device ordinal %d is beyond %d: %s", fn, dev, MAX_DEVICES,
+                  hipGetErrorString(e));
+    return TRL_EHIP;
+  }
+  std::lock_guard<std::mutex> lk(g_static_scratch_mu);
+  if (!g_static_scratch_ptr[dev]) {
+    void *p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));
+    if (e != hipSuccess || !p) {
+      trl_set_error("%s: hipGetSymbolAddress(static scratch) failed on device %d: %s", fn, dev, hipGetErrorString(e));
+      return TRL_EHIP;
+    }
+    g_static_scratch_ptr[dev] = (float *)p;
+  }
+  *out = g_static_scratch_ptr[dev];
+  return TRL_OK;
+}
+}  // namespace
+
+extern "C" int trl_ppo_loss(const float *mean, const float *log_std, const float *value,
+                            const float *action, const float *old_logp, const float *adv,
+                            const float *returns, int64_t B, int32_t A, double clip, double alpha,
+                            double beta, float *losses_out, float *dmean, float *dlog_std, float *dvalue,
+                            void *ws, void *stream) {
+  return ppo_loss_impl("trl_ppo_loss", mean, log_std, value, action, old_logp, adv, returns, B, A, clip, alpha, beta,
+                       losses_out, dmean, dlog_std, dvalue, ws, stream);
+}
+
+extern "C" int trl_ppo_loss_static(const float *mean, const float *log_std, const float *value, const float *action,
+                                   const float *old_logp, const float *adv, const float *returns, int64_t B,
+                                   int32_t A, double clip, double alpha, double beta, float *losses_out, float *dmean,
+                                   float *dlog_std, float *dvalue, void *stream) {
+  const char *fn = "trl_ppo_loss_static";
+  // sizes the fixed scratch cannot serve are refused here, before anything is enqueued
+  TRL_REQUIRE(A >= 1 && A <= MAX_PPO_A, "%s: A=%d is beyond the static scratch (1 <= A <= %d partial columns)", fn, A,
+              MAX_PPO_A);
+  TRL_REQUIRE(B >= 1 && B <= TRL_PPO_LOSS_STATIC_MAX_B, "%s: B=%lld is beyond the limit of this entry point (1 <= B <= %lld)",
+              fn, (long long)B, (long long)TRL_PPO_LOSS_STATIC_MAX_B);
+  float *ws = nullptr;
+  int rc = static_scratch(fn, &ws);
+  if (rc) return rc;
+  // every partial the finalize block reads is written by this call's first launch: nothing has to start at zero
+  return ppo_loss_impl(fn, mean, log_std, value, action, old_logp, adv, returns, B, A, clip, alpha, beta, losses_out,
+                       dmean, dlog_std, dvalue, ws, stream);
 }
 
 extern "C" int trl_normal_logp(const float *mean, const float *log_std, const float *action, int64_t B,
