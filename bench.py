@@ -53,6 +53,16 @@ def parse():
   ap.add_argument('--epochs', type=int, default=4)
   ap.add_argument('--capacity', type=int, default=None)
   ap.add_argument('--kernel-iters', type=int, default=50)
+  ap.add_argument('--rollout-layout', default='blocked', choices=['blocked', 'tn'],
+                  help='ppo: blocked = the rollout is kept as [N/E][T][E] (RolloutBuffer(layout="blocked"): flat per-group '
+                       'streams for the value pass and the GAE scan); tn = [T, N], the parity layout, minibatches in the '
+                       "reference's env-major order")
+  ap.add_argument('--block-envs', type=int, default=16, choices=[8, 16])
+  ap.add_argument('--only', default=None,
+                  help='run ONE kernel-timing entry and print its JSON (for a rocprofv3 kernel trace that holds nothing else): '
+                       'gae_cold_blocked, gae_warm_blocked, gae_cold_tn, gae_warm_tn, gather_wide_1024, gather_wide_256, '
+                       'gather_narrow_65536, gather_narrow_128, learn_kernel')
+  ap.add_argument('--no-sweep', action='store_true', help='ppo: skip the minibatch sweep (64 / 65,536 / 1,048,576)')
   ap.add_argument('--sampler', default='mt19937', choices=['mt19937', 'device'],
                   help='off-policy loops: mt19937 = bit-exact torch.randperm prefix on the host (parity mode); '
                        'device = Philox sampler on the GPU (throughput mode, not index-identical)')
@@ -139,14 +149,20 @@ def kernel_time_us(launch, iters):
   return a.elapsed_time(b) * 1e3 / iters
 
 
+PMC_FILES = ('r02_pmc_traffic.json', 'r01f_pmc_traffic.json')
+
+
 def pmc_traffic(key):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01f_pmc_traffic.json;
-  counters cannot be read from inside this process), or None when that launch was not profiled."""
-  try:
-    with open(os.path.join(ROOT, 'profiles', 'r01f_pmc_traffic.json')) as f:
-      return int(json.load(f)[key]['hbm_bytes'])
-  except (OSError, KeyError, ValueError):
-    return None
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json, made by
+  tools/pmc_traffic.py from two --pmc passes over `bench.py --only <entry>`; counters cannot be read from inside
+  this process), or None when that launch was not profiled."""
+  for name in PMC_FILES:
+    try:
+      with open(os.path.join(ROOT, 'profiles', name)) as f:
+        return int(json.load(f)[key]['hbm_bytes'])
+    except (OSError, KeyError, ValueError):
+      continue
+  return None
 
 
 def roofline(name, algo_bytes, us, note, traffic_key=None):
@@ -168,43 +184,131 @@ def make_rollout(T, N, obs_size, act_size, dev, seed):
   return obs, action, reward, done, last_next_obs
 
 
+def _tune_lib():
+  """The -DTRL_TUNING diagnostic build, for its flat-copy probe only (never for a timed product kernel)."""
+  import ctypes as C
+  path = os.path.join(ROOT, 'torchrl_amd', 'lib', 'libtrl_hip_tune.so')
+  if not os.path.exists(path):
+    return None
+  lib = C.CDLL(path)
+  lib.trl_tune_flat_copy.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_void_p]
+  lib.trl_tune_flat_copy.restype = C.c_int
+  return lib
+
+
+def gae_roofline(args, dev, T, N, layout, warm=False, with_ceilings=True):
+  """The GAE kernel alone (graph replay, events on the launch stream, caller-owned outputs).
+  Cold: the launches rotate over enough independent buffer sets (> 3 x 256 MiB) that every one reads its
+  inputs from HBM, not from the Infinity Cache; that is the roofline figure.  Warm: one set re-used."""
+  n = T * N
+  E = args.block_envs
+  algo = 16 * n + 4 * N          # r, v read + ret, adv written (4 B each) + bootstrap row
+  nsets = 1 if warm else max(2, int(3 * (256 << 20) / algo) + 1)
+  shape = (N // E, T, E) if layout == 'blocked' else (T, N)
+  sets = [(torch.randn(shape, device=dev), torch.randn(shape, device=dev), torch.randn(N, device=dev),
+           (torch.empty(shape, device=dev), torch.empty(shape, device=dev))) for _ in range(nsets)]
+  rot = {'i': 0}
+  fn = F.gae_blocked if layout == 'blocked' else F.gae
+
+  def launch():
+    s = sets[rot['i'] % nsets]
+    rot['i'] += 1
+    fn(s[0], s[1], s[2], 0.99, 0.95, out=s[3])
+
+  iters = max(args.kernel_iters, 2 * nsets) // nsets * nsets
+  us = kernel_time_us(launch, iters)
+  lay = ('blocked [N/%d][T][%d] (flat per-group streams)' % (E, E)) if layout == 'blocked' else '[T, N] (parity layout: 64 B row segments per workgroup)'
+  name = 'k_gae_pipe<%d,%d,false,1>' % ((E, 3) if layout == 'blocked' else (16, 2))
+  key = 'gae_%s_%s' % ('warm' if warm else 'cold', layout)
+  roof = roofline(name, algo, us, '16 B per (t, env) step x T*N = %d steps per launch, rollout layout %s; inputs %s'
+                  % (n, lay, 'resident in the Infinity Cache (one buffer set re-used)' if warm else
+                     'cold in HBM (%d rotating buffer sets)' % nsets),
+                  traffic_key=key if (T, N) == (2048, 4096) else None)
+  roof['entry'] = key
+  roof['profile'] = 'profiles/r02_%s_kernel_stats.csv' % key
+  if with_ceilings:
+    def copy_torch():      # a plain device copy moving the same bytes over the same rotating sets (two launches)
+      s = sets[rot['i'] % nsets]
+      rot['i'] += 1
+      s[3][0].copy_(s[0])
+      s[3][1].copy_(s[1])
+    us_copy = kernel_time_us(copy_torch, iters)
+    roof['copy_ceiling'] = {'GB/s': round(algo / us_copy / 1e3, 1), 'us': round(us_copy, 2),
+                            'note': 'torch device copy of the same bytes over the same buffer sets, same process (two launches)'}
+    roof['frac_of_copy_ceiling'] = round(us_copy / us, 4)
+    tune = _tune_lib()
+    if tune is not None:
+      def copy_flat():     # tools/copy_probe.hip's best flat copy: one launch, 256 persistent workgroups, 4 x 16 B per lane, nt
+        s = sets[rot['i'] % nsets]
+        rot['i'] += 1
+        rc = tune.trl_tune_flat_copy(s[0].data_ptr(), s[1].data_ptr(), s[3][0].data_ptr(), s[3][1].data_ptr(), n, 256,
+                                     torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+      us_flat = kernel_time_us(copy_flat, iters)
+      roof['flat_copy_probe'] = {'GB/s': round(algo / us_flat / 1e3, 1), 'us': round(us_flat, 2),
+                                 'note': 'one-launch fully coalesced non-temporal copy of both planes (diagnostic build, '
+                                         'tools/copy_probe.hip best setting): what a read-plus-write pass of these bytes reaches'}
+      roof['frac_of_flat_copy'] = round(us_flat / us, 4)
+  del sets
+  torch.cuda.empty_cache()
+  return roof
+
+
+def make_ppo_controller(args, dev):
+  hidden = tuple(int(h) for h in args.hidden.split(','))
+  torch.manual_seed(0)
+  return PPOController(3, 1, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3, clip_ratio=0.2, max_grad_norm=1.0,
+                       device=dev, hidden=hidden, graph=args.use_graph), hidden
+
+
 def bench_ppo(args, rank, world, dev):
   T, N, obs_size, act_size = args.T, args.N, 3, 1
-  hidden = tuple(int(h) for h in args.hidden.split(','))
   # 8 minibatches per epoch (T*N / 8 = 1,048,576 at the default shape): what PPO on thousands of
   # parallel envs is usually run with (4-8 minibatches per epoch), and 32 optimizer steps -- hence 32
-  # gradient all-reduces on N > 1 ranks -- per rollout.  --minibatch overrides (262,144 = 32 per epoch and
-  # 65,536 = 128 per epoch were the earlier defaults; DESIGN.md section 5 lists all three)
+  # gradient all-reduces on N > 1 ranks -- per rollout.  --minibatch overrides; the reference's own sizes
+  # (64) and SURVEY's 65,536 are in `minibatch_sweep`
   B = args.minibatch or max(1, (T * N) // 8)
   steps = args.steps if args.steps is not None else 5
   warmup = args.warmup if args.warmup is not None else 2
-  torch.manual_seed(0)
-  ctl = PPOController(obs_size, act_size, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3,
-                      clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden, graph=args.use_graph)
+  ctl, hidden = make_ppo_controller(args, dev)
   trace('controller built')
   obs, action, reward, done, last_next_obs = make_rollout(T, N, obs_size, act_size, dev, 1234 + rank)
   last_done = done[-1]
   n = T * N
+  blocked = args.rollout_layout == 'blocked'
+  if blocked:     # the rollout as RolloutBuffer(layout='blocked') holds it
+    E = args.block_envs
+    obs, action, reward = F.to_blocked(obs, E), F.to_blocked(action, E), F.to_blocked(reward, E)
   phase, keep = {}, {}
+
+  def prepare():
+    """compute_return over the rollout + the flat minibatch columns (blocked: consecutive slices of the blocked
+    order; tn: the reference's env-major order, examples/ppo.py:61-68)"""
+    returns, adv, logp, _values = ctl.compute_return_batched(obs, action, reward, last_next_obs, last_done,
+                                                             env_major_out=not blocked)
+    if blocked:
+      cols = (obs.reshape(n, obs_size), action.reshape(n, act_size), returns.reshape(n, 1), logp.reshape(n, act_size),
+              adv.reshape(n, 1))
+    else:
+      cols = (obs.transpose(0, 1).reshape(n, obs_size), action.transpose(0, 1).reshape(n, act_size),
+              returns.reshape(n, 1), logp.transpose(0, 1).reshape(n, act_size), adv.reshape(n, 1))
+    keep['cols'] = cols
+    return cols
+
+  def learn_slice(cols, s, e):
+    o, a, r, l, ad = cols
+    ctl.learn(o[s:e], a[s:e], None, None, None, r[s:e], l[s:e], ad[s:e])
 
   def step():
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e2 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    returns, adv, logp, _values = ctl.compute_return_batched(obs, action, reward, last_next_obs, last_done,
-                                                             env_major_out=True)
-    # minibatches in the reference's env-major order (examples/ppo.py:61-68)
-    obs_em = obs.transpose(0, 1).reshape(n, obs_size)
-    act_em = action.transpose(0, 1).reshape(n, act_size)
-    logp_em = logp.transpose(0, 1).reshape(n, act_size)
-    ret_em, adv_em = returns.reshape(n, 1), adv.reshape(n, 1)
-    keep.update(obs_em=obs_em, act_em=act_em, logp_em=logp_em, ret_em=ret_em, adv_em=adv_em)
+    cols = prepare()
     e1.record()
     trace('compute_return done')
     for _ in range(args.epochs):
       for s in range(0, n, B):
-        e = min(n, s + B)
-        ctl.learn(obs_em[s:e], act_em[s:e], None, None, None, ret_em[s:e], logp_em[s:e], adv_em[s:e])
+        learn_slice(cols, s, min(n, s + B))
     e2.record()
     trace('learn epochs issued')
     phase['ev'] = (e0, e1, e2)
@@ -216,47 +320,18 @@ def bench_ppo(args, rank, world, dev):
   learned = args.epochs * n * steps * world
   value = learned / dt
 
-  # --- GAE kernel alone (graph replay, events on the launch stream, caller-owned outputs).
-  # Cold: the launches rotate over enough independent buffer sets (> 3 x 256 MiB) that every one
-  # reads its inputs from HBM, not from the Infinity Cache; that is the roofline figure.
-  # Warm: one set re-used, inputs and outputs cache-resident (the case right after the value
-  # forward produced them); reported beside it.
-  algo = 16 * n + 4 * N          # r, v read + ret, adv written (4 B each) + bootstrap row
-  nsets = max(2, int(3 * (256 << 20) / algo) + 1)
-  sets = [(torch.randn(T, N, device=dev), torch.randn(T, N, device=dev), torch.randn(N, device=dev),
-           (torch.empty(T, N, device=dev), torch.empty(T, N, device=dev))) for _ in range(nsets)]
-  rot = {'i': 0}
-
-  def launch_cold():
-    s = sets[rot['i'] % nsets]
-    rot['i'] += 1
-    F.gae(s[0], s[1], s[2], 0.99, 0.95, out=s[3])
-
-  iters_cold = max(args.kernel_iters, 2 * nsets) // nsets * nsets
-  us = kernel_time_us(launch_cold, iters_cold)
-
-  def copy_cold():      # a plain device copy moving the same bytes over the same rotating sets
-    s = sets[rot['i'] % nsets]
-    rot['i'] += 1
-    s[3][0].copy_(s[0])
-    s[3][1].copy_(s[1])
-
-  us_copy = kernel_time_us(copy_cold, iters_cold)
-  s0 = sets[0]
-  us_warm = kernel_time_us(lambda: F.gae(s0[0], s0[1], s0[2], 0.99, 0.95, out=s0[3]), args.kernel_iters)
-  del sets
-  roof = roofline('k_gae_pipe', algo, us, '16 B per (t, env) step x T*N = %d steps per launch; inputs cold in '
-                  'HBM (%d rotating buffer sets); cache-resident inputs: %.2f us = %.0f GB/s'
-                  % (n, nsets, us_warm, algo / us_warm / 1e3),
-                  traffic_key='k_gae_pipe T=2048 N=4096' if (T, N) == (2048, 4096) else None)
-  roof['copy_ceiling'] = {'GB/s': round(algo / us_copy / 1e3, 1), 'us': round(us_copy, 2),
-                          'note': 'torch device copy of the same bytes over the same cold buffer sets, same process'}
-  roof['frac_of_copy_ceiling'] = round(us_copy / us, 4)
+  roof = gae_roofline(args, dev, T, N, args.rollout_layout)
+  warm = gae_roofline(args, dev, T, N, args.rollout_layout, warm=True, with_ceilings=False)
+  roof['note'] += '; cache-resident inputs: %.2f us = %.0f GB/s' % (warm['us_per_launch'], warm['achieved'])
+  other = 'tn' if blocked else 'blocked'
+  if N % args.block_envs == 0:
+    roof['other_layout'] = gae_roofline(args, dev, T, N, other, with_ceilings=False)
   share_learn = ms_learn / max(ms_return + ms_learn, 1e-9)
   extra = {'step_time_share': {'learn epochs (k_ac_learn + k_learn_reduce: see learn_kernel, MFMA-bound)': round(share_learn, 3),
                                'compute_return (k_ac_infer x2 + k_gae_pipe: see roofline, HBM-bound)': round(1 - share_learn, 3)},
-           'gae_steps_per_sec_kernel': round(n / (us * 1e-6), 1),
+           'gae_steps_per_sec_kernel': round(n / (roof['us_per_launch'] * 1e-6), 1),
            'gae_steps_per_sec_compute_return': round(n / (ms_return * 1e-3), 1),
+           'unique_transitions_per_sec': round(value / args.epochs, 1),
            'ms_compute_return': round(ms_return, 3), 'ms_learn_epochs': round(ms_learn, 3)}
   res = {
       'metric': 'learner transitions/sec (PPO: GAE + clipped loss + update)', 'value': round(value, 1),
@@ -265,36 +340,87 @@ def bench_ppo(args, rank, world, dev):
       'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': 'ppo_gae_clip: T=%d, N_envs=%d per GPU, MLP %s, obs 3, act 1' % (T, N, args.hidden),
                  'minibatch': B, 'n_epochs': args.epochs, 'learn_calls_per_step': args.epochs * ((n + B - 1) // B),
+                 'value_counts': 'every transition once per epoch (value = n_epochs x T x N / step time; '
+                                 'unique_transitions_per_sec = value / n_epochs)',
+                 'rollout_layout': ('blocked [N/%d][T][%d]' % (args.block_envs, args.block_envs)) if blocked else
+                 '[T, N], env-major minibatches',
                  'gamma': 0.99, 'lmbda': 0.95, 'clip_ratio': 0.2, 'parallelism': 'dp%d' % world,
                  'learn_step': ('hip-graph replay' if args.use_graph else 'eager') +
                  (': fused fwd+loss+bwd launch, reduce(+clip+Adam) launch' if ctl._fused is not None else '')},
       'roofline': roof,
   }
   res.update(extra)
+  cols = keep['cols']
+  if rank == 0 and world == 1 and not args.no_sweep:
+    res['minibatch_sweep'] = minibatch_sweep(args, ctl, cols, n, ms_return, learn_slice, B, dt / steps * 1e3)
   if ctl._fused is not None:
-    # the whole-step kernel pair alone (gradients only), graph-timed like the GAE kernel; FLOPs are the
-    # networks' own (no padding): forward, weight gradients, and input gradients of the hidden layers
-    f = ctl._fused
-    sl = slice(0, min(B, n))
-    a_ = tuple(keep[k][sl].contiguous() for k in ('obs_em', 'act_em', 'ret_em', 'logp_em', 'adv_em'))
-    us_l = kernel_time_us(lambda: f(*a_, 0.2, 0.5, 1e-3), max(10, args.kernel_iters // 2))
-    flops = 0
-    for lin in (f.critic_lin, f.actor_lin):
-      for i, m in enumerate(lin):
-        flops += (4 if i == 0 else 6) * m.in_features * m.out_features
-    flops *= a_[0].shape[0]
-    tf = flops / (us_l * 1e-6) / 1e12
-    res['learn_kernel'] = {'kernel': 'k_ac_learn+k_learn_reduce', 'bound': 'mfma', 'achieved': round(tf, 1),
-                           'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
-                           'us_per_launch': round(us_l, 2), 'flops_per_launch': int(flops),
-                           'note': 'forward + PPO loss + backward of critic and actor over one minibatch of %d '
-                                   '(exact f32 MFMA); %d FLOP per sample' % (a_[0].shape[0], flops // a_[0].shape[0])}
-    if len(f.critic_lin) == 2:
-      # one hidden layer: no hidden x hidden product; the last layer's dot products, their transposes and
-      # (fan-in <= 4) the layer-0 weight gradient run on the VALU, so the MFMA peak is not this shape's bound
-      res['learn_kernel']['note'] += ('; single hidden layer: most of these FLOPs are VALU FMAs (f32 VALU peak '
-                                      '%.1f TFLOP/s), frac is still quoted against the MFMA peak' % (F32_MFMA_PEAK_TFLOPS / 2))
+    res['learn_kernel'] = learn_kernel_roofline(args, ctl, cols, min(B, n))
   return res, dict(T=T, hidden=hidden, B=B, epochs=args.epochs)
+
+
+def minibatch_sweep(args, ctl, cols, n, ms_return, learn_slice, B_default, ms_default):
+  """The same step at the reference's own minibatch (64: examples/ppo.py:92; its default is 32), at SURVEY's 65,536
+  and at the bench default.  Small minibatches are timed on a bounded run of consecutive learn() calls and the
+  step is extrapolated (a whole 4-epoch step at B = 64 is 524,288 calls)."""
+  out = []
+  for Bm in (64, 65536, 1048576):
+    if Bm > n:
+      continue
+    calls_per_epoch = (n + Bm - 1) // Bm
+    if Bm == B_default:
+      ms_step, per_call, timed = ms_default, None, 'whole step (the headline run)'
+    else:
+      ncalls = min(calls_per_epoch, 4000 if Bm < 4096 else 256)
+      for s in range(0, min(n, 50 * Bm), Bm):        # warm-up
+        learn_slice(cols, s, min(n, s + Bm))
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for i in range(ncalls):
+        s = i * Bm
+        learn_slice(cols, s, min(n, s + Bm))
+      torch.cuda.synchronize()
+      per_call = (time.perf_counter() - t0) / ncalls * 1e3
+      ms_step = ms_return + args.epochs * calls_per_epoch * per_call
+      timed = '%d consecutive learn() calls, step extrapolated' % ncalls
+    tps = args.epochs * n / (ms_step * 1e-3)
+    row = {'minibatch': Bm, 'learn_calls_per_step': args.epochs * calls_per_epoch, 'ms_per_step': round(ms_step, 3),
+           'transitions_per_sec': round(tps, 1), 'unique_transitions_per_sec': round(tps / args.epochs, 1), 'timed': timed}
+    if per_call is not None:
+      row['us_per_learn_call'] = round(per_call * 1e3, 2)
+      if Bm < 4096:
+        row['bound'] = ('host issue + launch latency: a learn() is two dependent launches (k_ac_learn on %d strips of 32 '
+                        'samples = %d wavefronts of the chip\'s 1024, then k_learn_reduce + Adam) behind ~%d us of Python / '
+                        'ctypes; the GPU is idle most of the step.  What would lift it: K consecutive minibatches per launch '
+                        'in one persistent workgroup (weights in LDS, Adam between minibatches), DESIGN.md section 5'
+                        % ((Bm + 31) // 32, (Bm + 31) // 32, int(per_call * 1e3)))
+    out.append(row)
+  return out
+
+
+def learn_kernel_roofline(args, ctl, cols, Bk):
+  # the whole-step kernel pair alone (gradients only), graph-timed like the GAE kernel; FLOPs are the
+  # networks' own (no padding): forward, weight gradients, and input gradients of the hidden layers
+  f = ctl._fused
+  o, a, r, l, ad = (c[:Bk].contiguous() for c in cols)
+  us_l = kernel_time_us(lambda: f(o, a, r, l, ad, 0.2, 0.5, 1e-3), max(10, args.kernel_iters // 2))
+  flops = 0
+  for lin in (f.critic_lin, f.actor_lin):
+    for i, m in enumerate(lin):
+      flops += (4 if i == 0 else 6) * m.in_features * m.out_features
+  flops *= Bk
+  tf = flops / (us_l * 1e-6) / 1e12
+  out = {'kernel': 'k_ac_learn+k_learn_reduce', 'bound': 'mfma', 'achieved': round(tf, 1),
+         'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+         'us_per_launch': round(us_l, 2), 'flops_per_launch': int(flops), 'entry': 'learn_kernel',
+         'profile': 'profiles/r02_learn_kernel_kernel_stats.csv',
+         'note': 'forward + PPO loss + backward of critic and actor over one minibatch of %d '
+                 '(exact f32 MFMA); %d FLOP per sample' % (Bk, flops // Bk)}
+  if len(f.critic_lin) == 2:
+    # one hidden layer: no hidden x hidden product; the last layer's dot products, their transposes and
+    # (fan-in <= 4) the layer-0 weight gradient run on the VALU, so the MFMA peak is not this shape's bound
+    out['note'] += ('; single hidden layer: most of these FLOPs are VALU FMAs (f32 VALU peak '
+                    '%.1f TFLOP/s), frac is still quoted against the MFMA peak' % (F32_MFMA_PEAK_TFLOPS / 2))
+  return out
 
 
 def cpu_baseline_ppo(info):
@@ -404,10 +530,12 @@ def gather_roofline(dev, iters, rows, B, atari):
   us = kernel_time_us(lambda: ds._gather_index(idx, out), iters)
   algo = B * (2 * row_bytes + 8)
   name = 'k_gather_wide (one launch: wide chunks + narrow tail)' if atari else 'k_gather_narrow'
-  key = {(True, 1024): 'k_gather_wide atari B=1024', (False, 65536): 'k_gather_narrow pendulum B=65536'}.get((atari, B))
+  key = 'gather_%s_%d' % ('wide' if atari else 'narrow', B)
   r = roofline(name, algo, us, '(2 x %d B row + 8 B index) x B=%d rows gathered from a %d-row ring (%.1f GB)'
                % (row_bytes, B, rows, rows * ds.row_bytes / 1e9), traffic_key=key)
   r['transitions_per_sec'] = round(B / (us * 1e-6), 1)
+  r['entry'] = 'gather_%s_%d' % ('wide' if atari else 'narrow', B)
+  r['profile'] = 'profiles/r02_%s_kernel_stats.csv' % r['entry']
   del ds
   torch.cuda.empty_cache()
   return r
@@ -534,6 +662,28 @@ def cpu_baseline_offpolicy(info):
                     % (iters, dt, n, B), 'host_cpus': os.cpu_count()}
 
 
+def run_only(args, dev):
+  """ONE kernel-timing entry, nothing else on the GPU: the process a per-configuration rocprofv3 kernel trace
+  (profiles/r02_<entry>_kernel_stats.csv) and the PMC passes (tools/pmc_traffic.py) are taken from."""
+  e = args.only
+  if e.startswith('gae_'):
+    _, temp, layout = e.split('_')
+    return gae_roofline(args, dev, args.T, args.N, layout, warm=temp == 'warm', with_ceilings=False)
+  if e.startswith('gather_'):
+    _, kind, B = e.split('_')
+    atari = kind == 'wide'
+    return gather_roofline(dev, args.kernel_iters, 200_000 if atari else 1_000_000, int(B), atari=atari)
+  if e == 'learn_kernel':
+    ctl, _ = make_ppo_controller(args, dev)
+    n = args.minibatch or 1048576
+    g = torch.Generator(device=dev).manual_seed(1)
+    cols = (torch.randn(n, 3, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g),
+            torch.randn(n, 1, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g) - 1.0,
+            torch.randn(n, 1, device=dev, generator=g))
+    return learn_kernel_roofline(args, ctl, cols, n)
+  raise SystemExit('unknown --only entry %r' % e)
+
+
 def main():
   args = parse()
   if args.no_graph:
@@ -542,6 +692,9 @@ def main():
   args.use_graph = args.graph == 'on' or (args.graph == 'auto' and args.workload == 'dqn_atari' and args.f32_frames)
   rank, local, world = setup_dist(args)
   dev = torch.device('cuda', local)
+  if args.only:
+    print(json.dumps(run_only(args, dev)))
+    return
   if args.workload == 'ppo':
     res, info = bench_ppo(args, rank, world, dev)
   elif args.workload == 'a2c':

@@ -57,18 +57,33 @@ class A2CController(Controller):
     last_done [N] -> (returns, advantages, values), each [T, N] ([N, T] with env_major_out
     for the first two)."""
     need_hip(self.device, 'A2CController.compute_return')
-    T, N = reward.shape
+    blocked = reward.dim() == 3       # [N / E, T, E]: RolloutBuffer(layout='blocked'), see PPOController
+    if blocked:
+      G, T, E = reward.shape
+      N = G * E
+    else:
+      T, N = reward.shape
     with torch.no_grad():
       flat_obs = obs.reshape(T * N, -1)
       if self._fused is not None and self._fused.usable(flat_obs) and self._fused.usable(last_next_obs):
-        values = self._fused.forward(flat_obs, want_mean=False)[0].view(T, N)      # forward-only kernel
+        values = self._fused.forward(flat_obs, want_mean=False)[0]      # forward-only kernel
         bootstrap = self._fused.forward(last_next_obs, want_mean=False)[0]
       else:
-        values = self.ac_net.critic(flat_obs).view(T, N)
+        values = self.ac_net.critic(flat_obs)
         bootstrap = self.ac_net.critic(last_next_obs).view(N)
       bootstrap = torch.where(last_done.reshape(N) != 0, torch.zeros_like(bootstrap), bootstrap)
-      returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
-                           env_major_out=env_major_out)
+      if blocked:
+        values = values.view(G, T, E)
+        if G > 1 and reward.stride(0) != T * E:
+          buf = torch.empty((G, reward.stride(0) // E, E), dtype=torch.float32, device=reward.device)
+          buf[:, :T].copy_(values)
+          values = buf[:, :T]
+        returns, adv = F.gae_blocked(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
+                                     env_major_out=env_major_out)
+      else:
+        values = values.view(T, N)
+        returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
+                             env_major_out=env_major_out)
     return returns, adv, values
 
   def _learn_body(self, obs, action, returns):

@@ -67,8 +67,15 @@ class PPOController(Controller):
     """N envs at once: obs [T, N, obs_size], action [T, N, A], reward [T, N], last_next_obs
     [N, obs_size], last_done [N] -> (returns, advantages, log_probs [T, N, A], values [T, N]).
     With env_major_out, returns/advantages come back [N, T], the minibatch order of
-    examples/ppo.py:61-68."""
+    examples/ppo.py:61-68.
+
+    A rollout kept in the blocked layout (RolloutBuffer(layout='blocked'): obs [N / E, T, E, obs_size],
+    action [N / E, T, E, A], reward [N / E, T, E], E = 8 or 16) is recognised by its reward's three
+    dimensions: the value pass then writes its values in that order and the scan streams every env
+    group's [T, E] run (functional.gae_blocked); everything comes back blocked, [N / E, T, E(, A)]."""
     need_hip(self.device, 'PPOController.compute_return')
+    if reward.dim() == 3:
+      return self._compute_return_blocked(obs, action, reward, last_next_obs, last_done, done, masked, env_major_out)
     T, N = reward.shape
     with torch.no_grad():
       flat_obs = obs.reshape(T * N, -1)
@@ -89,6 +96,29 @@ class PPOController(Controller):
                            env_major_out=env_major_out)
       log_probs = F.normal_log_prob(mean, log_std, action.reshape(T * N, -1)).view(T, N, -1)
     return returns, adv, log_probs, values
+
+  def _compute_return_blocked(self, obs, action, reward, last_next_obs, last_done, done, masked, env_major_out):
+    G, T, E = reward.shape
+    N = G * E
+    with torch.no_grad():
+      flat_obs = obs.reshape(G * T * E, -1)
+      flat_act = action.reshape(G * T * E, -1)
+      if self._fused is not None and self._fused.usable(flat_obs) and self._fused.usable(last_next_obs):
+        values, _, log_probs = self._fused.forward(flat_obs, flat_act, want_mean=False)
+        bootstrap, _, _ = self._fused.forward(last_next_obs, want_mean=False)
+      else:
+        values, mean, log_std = self.ac_net.heads(flat_obs)
+        bootstrap = self.ac_net.critic(last_next_obs).view(N)
+        log_probs = F.normal_log_prob(mean, log_std, flat_act)
+      bootstrap = torch.where(last_done.reshape(N) != 0, torch.zeros_like(bootstrap), bootstrap.reshape(N))
+      values = values.view(G, T, E)
+      if G > 1 and reward.stride(0) != T * E:       # a [:, :T] slice of a larger-capacity buffer: give value the same strides
+        buf = torch.empty((G, reward.stride(0) // E, E), dtype=torch.float32, device=reward.device)
+        buf[:, :T].copy_(values)
+        values = buf[:, :T]
+      returns, adv = F.gae_blocked(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
+                                   env_major_out=env_major_out)
+    return returns, adv, log_probs.view(G, T, E, -1), values
 
   def _learn_body(self, obs, action, returns, old_log_probs, advantages):
     """Device work of one learn(): forward, fused loss, backward and (single rank) the update."""

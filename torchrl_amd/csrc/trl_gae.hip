@@ -634,3 +634,46 @@ extern "C" int trl_gae_reverse_scan_blocked(const float *reward, const float *va
                    returns, adv, dbg};
   return dispatch_pipe(block_envs, PF, U, a, (hipStream_t)stream);
 }
+
+#ifdef TRL_TUNING
+// ---- diagnostic build only: the flat copy the scan is measured against (tools/copy_probe.hip's best setting).
+// Both input planes to both output planes in ONE launch, fully coalesced, a persistent grid striding over the
+// whole range, UN x 16 B in flight per lane, non-temporal: what a read-plus-write pass over the scan's bytes can
+// reach on this part when it does nothing else.  bench.py times it over the same cold buffer sets.
+namespace {
+template <int UN>
+__global__ __launch_bounds__(256) void k_flat_copy(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b,
+                                                   f32x4 *__restrict__ oa, f32x4 *__restrict__ ob, size_t nq) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += stride * UN) {
+    f32x4 va[UN], vb[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const size_t j = i + u * stride;
+      if (j < nq) {
+        va[u] = __builtin_nontemporal_load(a + j);
+        vb[u] = __builtin_nontemporal_load(b + j);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const size_t j = i + u * stride;
+      if (j < nq) {
+        __builtin_nontemporal_store(va[u], oa + j);
+        __builtin_nontemporal_store(vb[u], ob + j);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int trl_tune_flat_copy(const float *a, const float *b, float *oa, float *ob, int64_t n, int32_t grid,
+                                  void *stream) {
+  const char *fn = "trl_tune_flat_copy";
+  TRL_REQUIRE(a && b && oa && ob && n > 0 && n % 4 == 0 && al16(a) && al16(b) && al16(oa) && al16(ob), "%s: bad arguments", fn);
+  hipLaunchKernelGGL(k_flat_copy<4>, dim3(grid > 0 ? grid : 256), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a,
+                     (const f32x4 *)b, (f32x4 *)oa, (f32x4 *)ob, (size_t)(n / 4));
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+#endif

@@ -616,7 +616,10 @@ class FusedPpoLearn:
   d loss / d parameter (no zero_grad needed); returns the [4] loss tensor
   (actor, critic, entropy, total)."""
 
-  MIN_BATCH = 256
+  # the reference's own minibatch sizes (32 default, 64 in its spec: examples/ppo.py:12, 92) take the whole-step
+  # kernel too (one or two 32-sample strips, two launches per learn()); below that, e.g. the last partial
+  # minibatch of an epoch, the layer-by-layer path
+  MIN_BATCH = 32
 
   @staticmethod
   def supports(critic_lin, actor_lin, log_std):

@@ -7,6 +7,14 @@ same).  Here one env step over all N envs is ONE row of preallocated `[T, N, .]`
 tensors (a single small H2D copy per column), the return/advantage pass is one batched call,
 and minibatches come out in the reference's order: env-major, sequential, last partial batch
 kept (`DataLoader(ds, batch_size)` at examples/ppo.py:68).
+
+`layout='blocked'` keeps the same rollout as `[N / E, T, E, .]` (E = 8 or 16 consecutive envs per group,
+a group's T steps contiguous): the value pass then writes its values in that order and the return /
+advantage scan streams one flat run per env group (csrc/trl_gae.hip, trl_gae_reverse_scan_blocked)
+instead of a 4 * E-byte segment of every `[T, N]` row.  Minibatches of a blocked rollout are
+consecutive slices of that order (a group's steps, E envs interleaved) -- the same samples per
+epoch as the reference's env-major order, cut into minibatches differently; use the default layout
+with `env_major()` where the reference's exact minibatch composition matters.
 """
 import numpy as np
 import torch
@@ -15,7 +23,12 @@ from .. import _lib
 
 
 class RolloutBuffer:
-  def __init__(self, n_envs, device=None, initial_steps=32):
+  def __init__(self, n_envs, device=None, initial_steps=32, layout='tn', block_envs=16):
+    if layout not in ('tn', 'blocked'):
+      raise ValueError("layout must be 'tn' or 'blocked'")
+    if layout == 'blocked' and (block_envs not in (8, 16) or n_envs % block_envs):
+      raise ValueError('the blocked layout needs block_envs 8 or 16 dividing n_envs=%d' % n_envs)
+    self.layout, self.block_envs = layout, block_envs
     self.n_envs = n_envs
     self._device = torch.device(device) if device is not None else None
     self._cap = initial_steps
@@ -36,6 +49,9 @@ class RolloutBuffer:
       raise _lib.TrlError('RolloutBuffer lives on a HIP device, not %s' % self._device)
 
   def _alloc(self, widths, cap):
+    if self.layout == 'blocked':
+      E = self.block_envs
+      return [torch.empty((self.n_envs // E, cap, E, w), dtype=torch.float32, device=self._device) for w in widths]
     return [torch.empty((cap, self.n_envs, w), dtype=torch.float32, device=self._device) for w in widths]
 
   def extend(self, transition_list):
@@ -57,7 +73,7 @@ class RolloutBuffer:
     if self._t == self._cap:
       new = self._alloc(self._widths, 2 * self._cap)
       for n, o in zip(new, self._cols):
-        n[:self._cap].copy_(o)
+        (n[:, :self._cap] if self.layout == 'blocked' else n[:self._cap]).copy_(o)
       self._cols, self._cap = new, 2 * self._cap
     slot = self._t % len(self._pin)
     if self._pin_ev[slot] is not None:
@@ -69,7 +85,10 @@ class RolloutBuffer:
     self._pin_ev[slot] = ev
     off = 0
     for col, w in zip(self._cols, self._widths):
-      col[self._t].copy_(self._stage[:, off:off + w])
+      if self.layout == 'blocked':
+        col[:, self._t].copy_(self._stage[:, off:off + w].view(-1, self.block_envs, w))
+      else:
+        col[self._t].copy_(self._stage[:, off:off + w])
       off += w
     self._last_next_obs.copy_(self._stage[:, off:])
     self._t += 1
@@ -78,8 +97,13 @@ class RolloutBuffer:
     self._t = 0
 
   def tensors(self):
-    """(obs [T,N,O], action [T,N,A], reward [T,N], done [T,N], last_next_obs [N,O])."""
+    """(obs [T,N,O], action [T,N,A], reward [T,N], done [T,N], last_next_obs [N,O]); blocked layout:
+    (obs [N/E,T,E,O], action [N/E,T,E,A], reward [N/E,T,E], done [N/E,T,E], last_next_obs [N,O])."""
     T = self._t
+    if self.layout == 'blocked':
+      # (width-1 columns: dropping the unit axis leaves strides (capacity * E, E, 1), what the scan takes)
+      obs, action, reward, done = (c[:, :T] for c in self._cols)
+      return obs, action, reward[..., 0], done[..., 0], self._last_next_obs
     obs, action, reward, done = (c[:T] for c in self._cols)
     return obs, action, reward[..., 0], done[..., 0], self._last_next_obs
 
