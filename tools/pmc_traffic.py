@@ -1,43 +1,43 @@
 #!/usr/bin/env python3
-"""profiles/*_pmc_traffic.json from two rocprofv3 --pmc passes over tools/kernels_once.py
-(FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, TCC counter budget).
+"""profiles/r02_pmc_traffic.json from the rocprofv3 --pmc passes of tools/profile_entries.sh: per bench entry
+(`bench.py --only <entry>`), the HBM bytes per launch of that entry's kernel.  FETCH_SIZE and WRITE_SIZE cannot
+share a pass (MI355X_MICROARCH.md, TCC counter budget), hence two files per entry.
 
-    python3 tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+    python3 tools/pmc_traffic.py gpurun_out/prof_r02 profiles/r02_pmc_traffic.json
 
-Units and the gfx950 correction follow the guide's HBM section: both counters are in KiB;
-FETCH_SIZE tallies the 128 B requests of wide streaming reads at 64 B, so it is doubled."""
+Units and the gfx950 correction follow the guide's HBM section: both counters are in KiB; FETCH_SIZE tallies the
+128 B requests of wide streaming reads at 64 B, so it is doubled (uncalibrated for the narrow gather's 4 B-per-lane
+record reads: there the raw and the doubled figure are both kept)."""
 import csv
+import glob
 import json
+import os
 import sys
 
-KEYS = [('k_gae_pipe', 'k_gae_pipe T=2048 N=4096'), ('k_gather_wide', 'k_gather_wide atari B=1024'),
-        ('k_gather_narrow', None)]
+KERNEL_OF = {'gae': 'k_gae_pipe', 'gather_wide': 'k_gather_wide', 'gather_narrow': 'k_gather_narrow'}
 
 
-def per_kernel(path, counter):
-  out = {}
-  for r in csv.DictReader(open(path)):
-    if r['Counter_Name'] != counter:
-      continue
-    out.setdefault((r['Kernel_Name'], int(r['Grid_Size'])), []).append(float(r['Counter_Value']) * 1024.0)
-  return out
+def mean_counter(path, counter, kernel):
+  vals = [float(r['Counter_Value']) * 1024.0 for r in csv.DictReader(open(path))
+          if r['Counter_Name'] == counter and kernel in r['Kernel_Name']]
+  return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
 def main():
-  fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+  src, out = sys.argv[1], sys.argv[2]
   res = {}
-  for (name, grid), vals in sorted(fetch.items()):
-    for sub, key in KEYS:
-      if sub not in name:
-        continue
-      if key is None:     # the narrow gather runs at two sizes: the Atari records' 12 B tail and Pendulum rows
-        key = 'k_gather_narrow pendulum B=65536' if grid >= 65536 * 4 else 'k_gather_narrow atari tail B=1024'
-      f = sum(vals) / len(vals)
-      w = write.get((name, grid), [0.0])
-      w = sum(w) / len(w)
-      res[key] = {'FETCH_SIZE_bytes_raw': f, 'fetch_bytes_corrected_x2': 2 * f, 'WRITE_SIZE_bytes': w,
-                  'hbm_bytes': 2 * f + w, 'launches': len(vals), 'kernel': name[:120]}
-  json.dump(res, open(sys.argv[3], 'w'), indent=1)
+  for fpath in sorted(glob.glob(os.path.join(src, '*_FETCH_SIZE.csv'))):
+    entry = os.path.basename(fpath)[:-len('_FETCH_SIZE.csv')]
+    wpath = os.path.join(src, entry + '_WRITE_SIZE.csv')
+    kernel = next(v for k, v in KERNEL_OF.items() if entry.startswith(k))
+    f, nf = mean_counter(fpath, 'FETCH_SIZE', kernel)
+    w, nw = mean_counter(wpath, 'WRITE_SIZE', kernel) if os.path.exists(wpath) else (None, 0)
+    if f is None or w is None:
+      continue
+    res[entry] = {'FETCH_SIZE_bytes_raw': f, 'fetch_bytes_corrected_x2': 2 * f, 'WRITE_SIZE_bytes': w,
+                  'hbm_bytes': 2 * f + w, 'launches': min(nf, nw), 'kernel': kernel,
+                  'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --only %s --kernel-iters 6`' % entry}
+  json.dump(res, open(out, 'w'), indent=1)
   print(json.dumps({k: int(v['hbm_bytes']) for k, v in res.items()}, indent=1))
 
 
