@@ -14,16 +14,16 @@ for E in (16, 8):
            torch.randn(N, device=dev), (torch.empty(N // E, T, E, device=dev), torch.empty(N // E, T, E, device=dev)))
           for _ in range(nsets)]
   for PF, U in ((3, 1),):
-    for dbg in (0, 48, 49, 9, 57, 3, 14):
-      os.environ['TRL_GAE_TUNE'] = '0,%d,%d,%d' % (PF, dbg, U)
+    for dbg, ck in ((48, 0), (48, 1), (49, 1), (14, 0), (14, 1), (6, 1), (50, 1)):
+      os.environ['TRL_GAE_TUNE'] = '0,%d,%d,%d,%d' % (PF, dbg, U, ck)
       us = graph_time_us([(lambda s=s: F.gae_blocked(s[0], s[1], s[2], 0.99, 0.95, out=s[3])) for s in sets])
-      print('blocked E=%2d PF=%d U=%d dbg=%2d [%s]  %6.1f us' % (
-          E, PF, U, dbg, ' '.join(n for b, n in ((1, 'nochain'), (2, 'nostore'), (4, 'nostage'), (8, 'nodma'), (16, 'ntst'), (32, 'ntld')) if dbg & b), us), flush=True)
-    for dbg in (48 + 256 + 2, 14 + 256):   # stamps (stores off: the stamps go into adv)
-      os.environ['TRL_GAE_TUNE'] = '0,%d,%d,%d' % (PF, dbg, U)
+      print('blocked E=%2d PF=%d U=%d ckpt=%d dbg=%2d [%s]  %6.1f us' % (
+          E, PF, U, ck, dbg, ' '.join(n for b, n in ((1, 'nochain'), (2, 'nostore'), (4, 'nostage'), (8, 'nodma'), (16, 'ntst'), (32, 'ntld')) if dbg & b), us), flush=True)
+    for dbg, ck in ((48 + 256 + 2, 0), (48 + 256 + 2, 1), (14 + 256, 1)):   # stamps (stores off: the stamps go into adv)
+      os.environ['TRL_GAE_TUNE'] = '0,%d,%d,%d,%d' % (PF, dbg, U, ck)
       s = sets[0]
       F.gae_blocked(s[0], s[1], s[2], 0.99, 0.95, out=s[3])
       torch.cuda.synchronize()
       st = s[3][1].reshape(-1)[:4 * (N // E)].reshape(-1, 4).median(0).values.tolist()
-      print('  stamps dbg=%d: scan %.0f cycles (%.1f / step), wave life %.0f, until first tile %.0f, first tile -> end %.0f'
-            % (dbg, st[0], st[0] / T, st[1], st[2], st[3]))
+      print('  stamps ckpt=%d dbg=%d: scan %.0f cycles (%.1f / step), wave life %.0f, until first tile %.0f, first tile -> end %.0f'
+            % (ck, dbg, st[0], st[0] / T, st[1], st[2], st[3]))

@@ -20,8 +20,9 @@
 // k_gae_pipe (the fast path) gives each role waves of its own and software-pipelines them
 // over LDS rings: at stage s two DMA waves stream tile s+PF straight into LDS, the worker
 // waves stage tile s and write out tile s-2, and the chain wave scans tile s-1; one barrier
-// per stage.  k_gae_tiled is the plain, unpipelined form for what the fast path does not
-// take (N % 4 != 0, unaligned bases, the masked extension).
+// per stage.  In reference mode the chain wave leaves only one value per 8 steps in LDS and the workers expand
+// the tile a stage later (template flag CKPT, below).  k_gae_tiled is the plain, unpipelined form for what the
+// fast path does not take (N % 4 != 0, unaligned bases).
 // HBM traffic is the algorithmic minimum: r and v read once (the v[t+1] operand re-reads the
 // same lines through L1/L2), ret and adv written once = 16 B per (t, env) step.
 //
@@ -129,7 +130,14 @@ __global__ __launch_bounds__(256) void k_gae_tiled(const float *__restrict__ rew
 // delta and the chain wave reads the tile's done values straight from the raw ring (the slot of
 // the tile being scanned is the one kept alive as the next tile's halo):
 //   delta = (r + (gamma * v[t+1]) * (1 - d)) - v;   gae = delta + (gamma_lambda * (1 - d)) * gae
-template <int E, int PF, bool MASKED, int U = 2>
+// CKPT (reference mode only): the chain wave keeps the running gae in registers and leaves ONE value per 8 steps in
+// LDS (a checkpoint) instead of writing every step back: an LDS store costs the issuing wave ~26 cycles whatever
+// its width (tools/chain_probe.hip: the chain is 10.9 cycles per step on the VALU, 6.5 more with the write-backs),
+// and the chain wave is the critical path.  One stage later the worker lanes, which have the issue slots to spare,
+// EXPAND the tile: lane (env, group) re-runs the group's 8 steps from the checkpoint above it -- same operations
+// in the same order, so the same bits -- and puts the 8 values where the write-out stage expects them.  The
+// pipeline is then one stage deeper (stage / scan / expand / write out).
+template <int E, int PF, bool MASKED, int U = 2, bool CKPT = false>
 __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ reward,
                                                   const float *__restrict__ value,
                                                   const float *__restrict__ done,
@@ -160,18 +168,21 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
   constexpr int TTP = TT + 4;       // row stride of the scan buffer, which is TRANSPOSED: [env][t], so
                                     // that a chain lane reads/writes 4 steps per ds_read/write_b128;
                                     // TTP % 64 == 4 (E 16, 32) or 36 (E 64) keeps 16 lanes on 16 bank quads
-  constexpr int NS = 3;             // scan ring: staged / being scanned / being written out
+  constexpr int NS = CKPT ? 4 : 3;  // scan ring: staged / being scanned / (CKPT: being expanded /) being written out
   constexpr int NR = PF + 2;        // raw ring: PF in flight + being read + halo of the previous tile
   constexpr int RPI = 256 / E;      // rows one 1 KiB DMA instruction covers
   constexpr int NP = MASKED ? 3 : 2;                // raw planes per tile: reward, value(, done)
   constexpr int SLOT = NP * PLANE;
   constexpr int IPW = 2 * U;                        // DMA instructions per plane per tile per wave
   constexpr int LPT = IPW * NP;                     // loads per tile per DMA wave
+  static_assert(!(CKPT && MASKED), "checkpointed chain: reference mode only");
+  constexpr int CPS = TT / 8 + 1;                   // checkpoints per env per tile (+ the tile's carry-in); odd
   // one array: see cdna_hip_programming.md on a second __shared__ object beside a DMA ring
-  __shared__ __attribute__((aligned(16))) float lds[NR * SLOT + NS * (E * TTP + TT * LD)];
+  __shared__ __attribute__((aligned(16))) float lds[NR * SLOT + NS * (E * TTP + TT * LD) + (CKPT ? NS * E * CPS : 1)];
   float *s_raw = lds;                               // [NR][NP][PLANE]  (reward plane, value plane, done plane)
-  float *s_d = lds + NR * SLOT;                     // [NS][E][TTP]    delta -> gae in place
+  float *s_d = lds + NR * SLOT;                     // [NS][E][TTP]    delta (-> gae in place unless CKPT)
   float *s_v = s_d + NS * E * TTP;                  // [NS][TT][LD]
+  float *s_cp = s_v + NS * TT * LD;                 // [NS][E][CPS]    CKPT: gae after each group of 8 steps
 
   // XCD-aware group order: blocks b and b + 8 share an XCD (its L2), so give each XCD a
   // contiguous run of env groups; neighbours that share a 128 B line then share an L2.
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int ntiles = (T + TT - 1) / TT;
-  const int nstages = ntiles + 2;
+  const int nstages = ntiles + (CKPT ? 3 : 2);
   // tile j (j = 0 is the LAST TT rows) covers t in [t_lo(j), t_hi(j))
   auto t_hi = [&](int j) { return T - j * TT; };
   auto t_lo = [&](int j) { const int lo = T - (j + 1) * TT; return lo < 0 ? 0 : lo; };
@@ -285,7 +296,35 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
           }
         }
       }
-      const int jo = s - 2;   // ---- write out tile s-2
+      if constexpr (CKPT) {   // ---- expand tile s-2: checkpoints -> gae of every step, in place of the deltas
+        const int je = s - 2;
+        constexpr int GPT = TT / 8;                      // groups per env per tile; E * GPT <= 256 lanes
+        if (je >= 0 && je < ntiles && m < E * GPT && !(dbg & 2)) {
+          const int rows = t_hi(je) - t_lo(je);
+          const int e = m / GPT, g8 = 8 * (m % GPT);
+          if (g8 < rows) {
+            float *sd_e = s_d + (je % NS) * E * TTP + e * TTP + g8;
+            float gae = s_cp[(je % NS) * E * CPS + e * CPS + (g8 >> 3) + 1];
+            const f32x4 dl = *(const f32x4 *)sd_e, dh = *(const f32x4 *)(sd_e + 4);
+            f32x4 ol, oh;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {               // rows beyond a partial tile's end are not stepped
+              const float nx = __fadd_rn(dh[i], __fmul_rn(gl, gae));
+              gae = g8 + 4 + i < rows ? nx : gae;
+              oh[i] = gae;
+            }
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+              const float nx = __fadd_rn(dl[i], __fmul_rn(gl, gae));
+              gae = g8 + i < rows ? nx : gae;
+              ol[i] = gae;
+            }
+            *(f32x4 *)(sd_e + 4) = oh;
+            *(f32x4 *)sd_e = ol;
+          }
+        }
+      }
+      const int jo = s - (CKPT ? 3 : 2);   // ---- write out tile s-2 (CKPT: s-3, expanded in the previous stage)
       if (jo >= 0 && jo < ntiles && !(dbg & 2)) {
         const int lo = t_lo(jo), hi = t_hi(jo);
         const float *sd = s_d + (jo % NS) * E * TTP, *sv = s_v + (jo % NS) * TT * LD;
@@ -344,8 +383,7 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
           }
         }
       }
-      // LDS traffic only: the output stores stay in flight across the barrier (a __syncthreads() here waits
-      // for vmcnt(0) as well, i.e. one store round trip per stage: 16 of the kernel's 30 us)
+      // LDS traffic only is waited for: the output stores stay in flight across the barrier
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -368,11 +406,14 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
         float *sd = s_d + (jc % NS) * E * TTP + lane * TTP;   // this env's row of the transposed tile
         const float *sm = s_raw + (jc % NR) * SLOT + 2 * PLANE + lane;   // MASKED: done[tl] at sm[tl * E]
         int top = rows;
+        float *cp = s_cp + (jc % NS) * E * CPS + lane * CPS;   // CKPT: this env's checkpoints of the tile
+        if (CKPT) cp[(rows + 7) >> 3] = gae;                    // the tile's carry-in, above its top group
         for (; top & 7; --top) {   // ragged head of a partial tile, one step at a time
           const float c = MASKED ? __fmul_rn(gl, __fsub_rn(1.0f, sm[(top - 1) * E])) : gl;
           gae = __fadd_rn(sd[top - 1], __fmul_rn(c, gae));
-          sd[top - 1] = gae;
+          if (!CKPT) sd[top - 1] = gae;
         }
+        if (CKPT && (rows & 7)) cp[top >> 3] = gae;             // below the partial top group
         if (MASKED) {
           // per-step coefficient gamma_lambda * (1 - done): formed off the dependent chain from
           // the raw done plane, one group of 8 steps ahead
@@ -429,8 +470,12 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
           lo4[2] = gae = __fadd_rn(d[0][2], __fmul_rn(gl, gae));
           lo4[1] = gae = __fadd_rn(d[0][1], __fmul_rn(gl, gae));
           lo4[0] = gae = __fadd_rn(d[0][0], __fmul_rn(gl, gae));
-          *(f32x4 *)(sd + g + 4) = hi4;
-          *(f32x4 *)(sd + g) = lo4;
+          if constexpr (CKPT) {
+            cp[g >> 3] = gae;           // one value per group; the workers re-run the group's steps from the one above
+          } else {
+            *(f32x4 *)(sd + g + 4) = hi4;
+            *(f32x4 *)(sd + g) = lo4;
+          }
         };
         if (rows == TT) {
           // full tile: straight-line code, no loop bookkeeping on the chain's issue slots;
@@ -479,6 +524,9 @@ __global__ __launch_bounds__(448) void k_gae_pipe(const float *__restrict__ rewa
   }
 }
 
+// 1: the checkpointed chain (k_gae_pipe<..., CKPT = true>) is what reference-mode launches run
+#define TRL_GAE_CKPT_DEFAULT 1
+
 struct PipeArgs {
   const float *reward, *value, *done, *bootstrap;
   int T, N;
@@ -487,14 +535,15 @@ struct PipeArgs {
   int64_t in_ts, out_ts;   // blocked layouts: rows allocated per env group (0: the plane is [T, N])
   float *returns, *adv;
   int dbg;
+  bool ckpt;               // checkpointed chain (reference mode only)
 };
 
-template <int E, int PF, bool MASKED, int U = 2>
+template <int E, int PF, bool MASKED, int U = 2, bool CKPT = false>
 int launch_pipe(const PipeArgs &a, hipStream_t st) {
   const int ngroups = (int)trl_cdiv(a.N, E);
   const int64_t in_gs = a.in_ts ? a.in_ts * E : E, out_gs = a.out_ts ? a.out_ts * E : E;
   const int in_rs = a.in_ts ? E : a.N, out_rs = a.out_ts ? E : a.N;
-  hipLaunchKernelGGL((k_gae_pipe<E, PF, MASKED, U>), dim3(ngroups), dim3(448), 0, st, a.reward, a.value, a.done,
+  hipLaunchKernelGGL((k_gae_pipe<E, PF, MASKED, U, CKPT>), dim3(ngroups), dim3(448), 0, st, a.reward, a.value, a.done,
                      a.bootstrap, a.T, a.N, a.gamma, a.gl, a.out_nt, ngroups, in_gs, in_rs, out_gs, out_rs, a.returns,
                      a.adv, a.dbg);
   TRL_CHECK_LAUNCH("trl_gae_reverse_scan");
@@ -510,6 +559,16 @@ int dispatch_pipe(int E, int PF, int U, const PipeArgs &a, hipStream_t st) {
   // half-size tiles (64 rows at E = 16): twice the stages, half the pipeline fill and drain;
   // 36.6 -> 32.5 us cold at T = 2048, N = 4096
   if (U == 0) U = E == 16 ? 1 : 2;
+  if (a.ckpt && !masked) {
+#define TRL_CKPT_CASE(e, pf, u) \
+  if (E == e && PF == pf && U == u) return launch_pipe<e, pf, false, u, true>(a, st);
+    TRL_CKPT_CASE(16, 2, 1) TRL_CKPT_CASE(16, 3, 1) TRL_CKPT_CASE(8, 2, 1) TRL_CKPT_CASE(8, 3, 1)
+    TRL_CKPT_CASE(32, 2, 2) TRL_CKPT_CASE(64, 2, 2)
+#ifdef TRL_TUNING
+    TRL_CKPT_CASE(16, 4, 1) TRL_CKPT_CASE(16, 2, 2) TRL_CKPT_CASE(16, 3, 2)
+#endif
+#undef TRL_CKPT_CASE
+  }
 #define TRL_PIPE_CASE(e, pf, m, u) \
   if (E == e && PF == pf && masked == m && U == u) return launch_pipe<e, pf, m, u>(a, st);
   // production set
@@ -576,12 +635,12 @@ extern "C" int trl_gae_reverse_scan(const float *reward, const float *value, con
   if (aligned && (!masked || al16(done))) {
     // Envs per workgroup: 16 (a 64 B row segment) while that gives at most one workgroup per
     // CU (the pipelined kernel holds most of a CU's LDS), then wider segments.
-    int E = 0, PF = 0, dbg = 0, U = 0;
+    int E = 0, PF = 0, dbg = 0, U = 0, ckpt = TRL_GAE_CKPT_DEFAULT;
 #ifdef TRL_TUNING   // diagnostic build only (tools/gae_sweep.py); the production library never reads the environment
-    if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d,%d", &E, &PF, &dbg, &U);
+    if (const char *tune = getenv("TRL_GAE_TUNE")) sscanf(tune, "%d,%d,%d,%d,%d", &E, &PF, &dbg, &U, &ckpt);
 #endif
     const PipeArgs a{reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
-                     out_layout == TRL_LAYOUT_NT, 0, 0, returns, adv, dbg};
+                     out_layout == TRL_LAYOUT_NT, 0, 0, returns, adv, dbg, ckpt != 0};
     return dispatch_pipe(E, PF, U, a, st);
   }
   return launch<16>(masked, reward, value, done, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
@@ -612,11 +671,11 @@ extern "C" int trl_gae_reverse_scan_blocked(const float *reward, const float *va
               "%s: every plane must be 16-byte aligned", fn);
   if (T == 0 || N == 0) return TRL_OK;
   const bool masked = mode == TRL_GAE_MASKED;
-  int PF = 0, dbg = 0, U = 0;
+  int PF = 0, dbg = 0, U = 0, ckpt = TRL_GAE_CKPT_DEFAULT;
 #ifdef TRL_TUNING
   if (const char *tune = getenv("TRL_GAE_TUNE")) {
     int e_ignored = 0;
-    sscanf(tune, "%d,%d,%d,%d", &e_ignored, &PF, &dbg, &U);
+    sscanf(tune, "%d,%d,%d,%d,%d", &e_ignored, &PF, &dbg, &U, &ckpt);
   }
 #endif
   if (U == 0) U = 1;
@@ -631,7 +690,7 @@ extern "C" int trl_gae_reverse_scan_blocked(const float *reward, const float *va
 #endif
   const PipeArgs a{reward, value, masked ? done : nullptr, bootstrap, (int)T, (int)N, gamma, gamma_lambda,
                    out_layout == TRL_LAYOUT_NT, in_t_stride, out_layout == TRL_LAYOUT_BLOCKED ? out_t_stride : 0,
-                   returns, adv, dbg};
+                   returns, adv, dbg, ckpt != 0};
   return dispatch_pipe(block_envs, PF, U, a, (hipStream_t)stream);
 }
 
