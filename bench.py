@@ -553,7 +553,13 @@ def bench_offpolicy(args, rank, world, dev, atari):
   g = torch.Generator(device=dev).manual_seed(100 + rank)
   torch.manual_seed(0)
   if atari:
-    cap = args.capacity or 1_000_000
+    # the largest ring that fits one GPU (BASELINE config 4: 10 M transitions only fit sharded, 70.6 GB per GPU on 8):
+    # 4,000,000 records x 56,480 B = 226 GB of the 288 GB, or what 85 % of the free HBM holds
+    if args.capacity:
+      cap = args.capacity
+    else:
+      free, _ = torch.cuda.mem_get_info()
+      cap = max(8192, min(4_000_000, int(0.85 * free) // 56480 // 8192 * 8192))
     B = args.minibatch or 256
     # frames stay uint8 from the ring to the first layer's operand fetch (csrc/trl_linear_u8.hip); --f32-frames
     # hands the learner float32 frames instead (the cast fused into the gather), the earlier path

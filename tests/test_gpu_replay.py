@@ -276,6 +276,61 @@ def test_large_ring_properties():
   assert torch.equal(nobs[:, 1], r + 1.25) and torch.equal(done[:, 0], r % 2)
 
 
+def test_atari_ring_past_4gib_offsets_and_wrap():
+  """BASELINE config 4 at size: a 100,000-row ring of Atari-shaped uint8 records (56,480 B each = 5.6 GB, so byte
+  offsets pass 2^32 at record 76,045) that has wrapped.  Every gathered value is checked against a closed form of
+  (global row id, column, position), at indices on both sides of the wrap, on both sides of the 4 GiB offset, at the
+  ends and at random: index gather (device and host indices), range gather across the boundary, the uint8 -> float32
+  cast path and the 12 B narrow tail that rides in the same launch."""
+  cap, extra, K = 100_000, 3_333, 28224
+  free, _ = torch.cuda.mem_get_info()
+  if free < 9 * (1 << 30):
+    pytest.skip('needs 9 GiB of free HBM')
+  dt = [torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32]
+  ds = TensorTupleDataset(size=cap, device=DEV, storage_dtypes=dt, gather_dtypes=dt)
+  j = torch.arange(K, device=DEV, dtype=torch.int64).view(1, K)
+
+  def frames(rows, a, b):       # rows: int64 global row ids [k] -> uint8 [k, 84, 84, 4]
+    return ((rows.view(-1, 1) * a + j * b + (j >> 8)) & 255).to(torch.uint8).view(-1, 84, 84, 4)
+
+  def tail(rows):
+    r = rows.view(-1, 1).float()
+    return (r % 6), (r % 3) - 1.0, (rows.view(-1, 1) % 200 == 0).float()
+
+  for lo in range(0, cap + extra, 4096):
+    rows = torch.arange(lo, min(lo + 4096, cap + extra), device=DEV, dtype=torch.int64)
+    act, rew, done = tail(rows)
+    ds.extend(frames(rows, 7, 13), act, rew, frames(rows, 11, 5), done)
+  assert len(ds) == cap and ds.row_bytes * cap > (1 << 32) and ds._head == extra
+  stride = ds.row_bytes
+  p32 = (1 << 32) // stride                       # the physical record whose bytes straddle 2^32
+  special = []
+  for phys in (0, 1, cap - 1, cap - 2, p32 - 1, p32, p32 + 1, p32 + 2):
+    special.append((phys - extra) % cap)          # logical index of that physical record
+  special += [0, 1, cap - 1, -1, -cap]
+  g = torch.Generator().manual_seed(11)
+  idx = torch.cat([torch.tensor(special, dtype=torch.int64), torch.randint(0, cap, (1500,), generator=g)])
+  rows = (idx % cap) + extra                      # global row id of logical index i (0 = oldest survivor)
+  exp = (frames(rows.to(DEV), 7, 13),) + tail(rows.to(DEV))[:2] + (frames(rows.to(DEV), 11, 5), tail(rows.to(DEV))[2])
+  for index in (idx.to(DEV), idx):                # device indices, then host indices (staged through pinned memory)
+    got = ds[index]
+    for c, (a, b) in enumerate(zip(got, exp)):
+      assert a.dtype == b.dtype and torch.equal(a, b), 'column %d' % c
+  # a contiguous logical range across the 4 GiB boundary and across the wrap
+  for lo in ((p32 - extra) % cap - 40, cap - extra - 40):
+    got = ds[lo:lo + 80]
+    rr = torch.arange(lo, lo + 80, device=DEV, dtype=torch.int64) + extra
+    assert torch.equal(got[0], frames(rr, 7, 13)) and torch.equal(got[3], frames(rr, 11, 5))
+    assert torch.equal(got[1], tail(rr)[0])
+  # the cast path (frames handed out as float32, the reference's dtype) on the special indices
+  ds._gather_dtypes = [torch.float32] * 5
+  got = ds[idx[:len(special)].to(DEV)]
+  assert got[0].dtype == torch.float32 and torch.equal(got[0], exp[0][:len(special)].float())
+  assert torch.equal(got[3], exp[3][:len(special)].float())
+  del ds
+  torch.cuda.empty_cache()
+
+
 def test_device_sampler_distinct_uniform_reproducible():
   """Throughput-mode sampler (trl_sample_indices): distinct indices in range, a function of
   (seed, call number) only, uniform over the rows; the gathered batch is ds[indices]."""
