@@ -387,12 +387,16 @@ def minibatch_sweep(args, ctl, cols, n, ms_return, learn_slice, B_default, ms_de
            'transitions_per_sec': round(tps, 1), 'unique_transitions_per_sec': round(tps / args.epochs, 1), 'timed': timed}
     if per_call is not None:
       row['us_per_learn_call'] = round(per_call * 1e3, 2)
-      if Bm < 4096:
-        row['bound'] = ('host issue + launch latency: a learn() is two dependent launches (k_ac_learn on %d strips of 32 '
-                        'samples = %d wavefronts of the chip\'s 1024, then k_learn_reduce + Adam) behind ~%d us of Python / '
-                        'ctypes; the GPU is idle most of the step.  What would lift it: K consecutive minibatches per launch '
-                        'in one persistent workgroup (weights in LDS, Adam between minibatches), DESIGN.md section 5'
-                        % ((Bm + 31) // 32, (Bm + 31) // 32, int(per_call * 1e3)))
+      if Bm < 4096 and ctl._fused is not None:
+        # the device side of one learn() alone (the launch pair replayed from a HIP graph, no host in between)
+        o, a, r, l, ad = (c[:Bm] for c in cols)
+        row['us_gpu_per_learn_call'] = round(kernel_time_us(lambda: ctl._fused(o, a, r, l, ad, 0.2, 0.5, 1e-3,
+                                                                                adam=ctl.ac_net_optim), 200), 2)
+        row['bound'] = ('latency, not throughput: a learn() is two dependent launches (k_ac_learn on %d strips of 32 samples = '
+                        '%d of the chip\'s 1024 wavefronts, then k_learn_reduce + Adam); us_gpu_per_learn_call is the pair '
+                        'replayed back to back from a HIP graph, us_per_learn_call adds the host (Python + ctypes).  '
+                        'DESIGN.md section 5 has the breakdown and what a multi-minibatch launch would buy'
+                        % ((Bm + 31) // 32, (Bm + 31) // 32))
     out.append(row)
   return out
 

@@ -192,6 +192,27 @@ __device__ __forceinline__ float row_sum32_dw4(const float *grow, const float *s
   return (s0 + s1) + (s2 + s3);
 }
 
+// Last-layer weight gradient per FEATURE instead of per lane-partial (wide two-output variant): lane = feature f
+// reads its own activation row h[f][0..31] of the strip and, as broadcast 16 B reads, the NO rows of the output
+// gradient gout[n][0..31], and adds  dwl[n] += sum_row gout[n][row] h[f][row].  One accumulator register per
+// (block, output) instead of 32: 4 blocks x 2 outputs no longer need 256 registers, nor a split launch.
+template <int NO>
+__device__ __forceinline__ void rows_dwl(const float *hrow, const float *sGo, float (&dwl)[NO]) {
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = ld4(hrow + 4 * i);
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 x = ld4(sGo + n * LDT + 4 * i);
+      a0 = fmaf(v[i].x, x.x, a0); a1 = fmaf(v[i].y, x.y, a1); a2 = fmaf(v[i].z, x.z, a2); a3 = fmaf(v[i].w, x.w, a3);
+    }
+    dwl[n] += (a0 + a1) + (a2 + a3);
+  }
+}
+
 // ---- forward pieces, shared by the learner kernel and the inference kernel
 // layer 0: h1^T = relu(W0 x^T + b0); x^T from the strip's LDS tile, k walked in natural order
 template <int LDW0>
@@ -335,7 +356,11 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;             // floats of the x tile (+ a dummy slot for idle prefetch lanes)
-  constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0);   // per-wave scratch
+  // WLV: 4 hidden blocks x 2 outputs.  The last layer's weight gradient is accumulated per feature from LDS tiles
+  // (rows_dwl) instead of per lane in 256 registers; the activation tile and the output-gradient rows it reads
+  // take the place D == 3 uses for h1^T (+ 4 rows)
+  constexpr bool WLV = HB * NO > 4;
+  constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0) + (WLV ? 64 * LDT + 4 * LDT : 0);   // per-wave scratch
   constexpr int WTP = (WT + 3) & ~3;
   __shared__ __align__(16) float sW0[HB * 64 * LDW0];
   __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];    // W1[n][k]
@@ -359,7 +384,8 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   stage_weights<D, LDW0, NO, true, HB>(a, sW0, sW1, sW1T, sWL, sB, tid);
   float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
   float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
-  float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T
+  float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T; (WLV) the block's activations
+  float *sGo = sH + 64 * LDT;       // [4][LDT]       (WLV) gradient w.r.t. the outputs, one row per output
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;   // rows >= K0 stay zero for good
   __syncthreads();
   STAMP(1);
@@ -372,16 +398,20 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // the whole forward and the backward of its own two blocks (blocks qb0 .. qb0 + NBQ - 1), recomputing a
   // block's activations there (RC below) instead of holding all four from the forward; the two z write
   // disjoint entries of the same partial set, z = 0 also the scalars and the last layer's bias gradient.
-  constexpr int NBQ = HB * NO > 4 ? HB / 2 : HB;
+  // (kept for reference: the split is no longer taken -- WLV above removed the register pressure it answered)
+  constexpr int NBQ = HB;
   constexpr bool RC = NBQ != HB;
   const int qb0 = RC ? (int)blockIdx.z * NBQ : 0;
+  float dwlv[NBQ][NO];          // WLV: last-layer weight gradient of feature `lane` of block q
   float vdb0[NBQ], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
   // fan-in <= 4: dW0[lane][k] accumulates per lane on the VALU (row_sum32_dw4) instead of in accW0
   const bool w0v = HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
   float dw0v[NBQ][4];
-  f32x16 dWL[NBQ][NO][2];
+  f32x16 dWL[WLV ? 1 : NBQ][NO][2];
 #pragma unroll
   for (int qb = 0; qb < NBQ; ++qb) {
+#pragma unroll
+    for (int n = 0; n < NO; ++n) dwlv[qb][n] = 0.f;
     vdb0[qb] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dw0v[qb][k] = 0.f;
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   for (int n = 0; n < NO; ++n) {
     dbL[n] = 0.f;
 #pragma unroll
-    for (int qb = 0; qb < NBQ; ++qb)
+    for (int qb = 0; qb < (WLV ? 1 : NBQ); ++qb)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -636,6 +666,16 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     if (RC) fwd_layer0<LDW0>(h1q[0], sX, sW0 + (qb0 + qb) * 64 * LDW0, sB + (qb0 + qb) * 64, ksteps0, half, r32);
     const f32x16 (&hl)[2] = D == 3 ? h2 : h1q[RC ? 0 : qb];
     const float *sWLq = sWL + (qb0 + qb) * NO * 64;
+    if constexpr (WLV) {
+      // the block's activations and the output gradients as [.][row] tiles; lane = feature sums its row
+      put_tile(sH, hl, half, r32);
+      if (qb == 0 && half == 0) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) sGo[n * LDT + r32] = gout[n];
+      }
+      wave_lds_fence();
+      rows_dwl<NO>(sH + lane * LDT, sGo, dwlv[qb]);
+    }
     // ---- last layer backward (VALU): dWL, dbL partials; g = (WL^T gout) * (hl > 0)
     f32x16 g[2];
 #pragma unroll
@@ -650,8 +690,10 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
           t[1] = fmaf(w4.y, gout[n], t[1]);
           t[2] = fmaf(w4.z, gout[n], t[2]);
           t[3] = fmaf(w4.w, gout[n], t[3]);
+          if constexpr (!WLV) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dWL[qb][n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[qb][n][kb][4 * q + i]);
+            for (int i = 0; i < 4; ++i) dWL[qb][n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[qb][n][kb][4 * q + i]);
+          }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = hl[kb][4 * q + i] > 0.f ? t[i] : 0.f;
@@ -776,12 +818,16 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     for (int qb = 0; qb < NBQ; ++qb)
 #pragma unroll
       for (int n = 0; n < NO; ++n) {
-        put_tile(sG, dWL[qb][n], half, r32);
-        wave_lds_fence();
-        s = 0.f;
-        for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
-        vec_wl[qb][n] = s;
-        wave_lds_fence();
+        if constexpr (WLV) {
+          vec_wl[qb][n] = dwlv[qb][n];           // already per feature
+        } else {
+          put_tile(sG, dWL[qb][n], half, r32);
+          wave_lds_fence();
+          s = 0.f;
+          for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
+          vec_wl[qb][n] = s;
+          wave_lds_fence();
+        }
       }
   }
   // scalars: wave sums (fixed butterfly order)
@@ -1235,12 +1281,12 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   }
   const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
   if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
-    // (4 blocks x 2 outputs would need 256 accumulator registers for the last layer's gradient alone)
+    // (4 blocks x 2 outputs: the last layer's weight gradient is accumulated per feature from LDS tiles, WLV)
     TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
     if (hmax <= 128 && NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 2>), grid, block, 0, st, P);
     else if (hmax <= 128) hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 2>), grid, block, 0, st, P);
     else if (NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 4>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 4>), dim3(grid.x, 2, 2), block, 0, st, P);   // NBQ = 2
+    else hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 4>), grid, block, 0, st, P);   // WLV: per-feature dWL
   } else {
   TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
   TRL_LEARN_CASE(2, 2, 1) TRL_LEARN_CASE(2, 2, 2) TRL_LEARN_CASE(2, 2, 4)
