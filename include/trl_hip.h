@@ -413,6 +413,46 @@ int trl_dqn_learn_fused_u8(const trl_mlp_desc *q_net, const trl_mlp_desc *target
                            int64_t B, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
                            float *loss_out, const trl_adam_args *opt, void *ws, void *stream);
 
+/* ------------------------------------------------------------------ env-step side: rollout push, exploration ("next" rows f2-f4)
+ * trl_rollout_push: one env step's transitions -> the on-policy rollout columns, ONE launch.  Replaces the per-env
+ * `buffer.extend([transition])` of examples/ppo.py:28-35 / examples/a2c.py:26-28 (one torch.cat per column per env
+ * per step, torchrl/utils/storage.py:7-16).  rows_pinned: PINNED host memory [N, sum(width)] float32, env n's
+ * packed row = its columns side by side; the kernel reads it directly (no DMA-engine copy in the stream).
+ * Column i of env n goes to dst[i] + (n / block_envs[i]) * group_stride[i] + (n % block_envs[i]) * width[i]
+ * (floats): block_envs = 1, group_stride = width for a dense [N, width] destination (row t of a [T, N, width]
+ * rollout); block_envs = E, group_stride = capacity * E * width for the blocked layout [N / E, capacity, E, width]
+ * with dst[i] already offset to step t. */
+typedef struct {
+  int32_t ncols;
+  int32_t width[TRL_MAX_COLS];
+  int32_t block_envs[TRL_MAX_COLS];
+  int64_t group_stride[TRL_MAX_COLS];
+  float *dst[TRL_MAX_COLS];
+} trl_rollout_cols;
+int trl_rollout_push(const float *rows_pinned, int64_t N, const trl_rollout_cols *cols, void *stream);
+
+/* Exploration drawn on the device, one launch per act() (the reference draws on the host from numpy's global
+ * generator after a device -> host copy of the network output: dqn_controller.py:57-59, ddpg_controller.py:92-94;
+ * a2c_controller.py:21-27 and ppo_controller.py:24-30 sample with torch and copy back).  Counter-based generator
+ * (Philox-4x32-10): the result is a function of (seed, call, row) alone, `call` numbered by the caller.  Same action
+ * DISTRIBUTIONS as the reference, not the same draws.
+ *   epsilon_greedy: q [n, A] -> actions [n] int64: argmax with probability 1 - eps + eps / A, any other action with
+ *                   eps / A (the categorical of dqn_controller.py:16-22).
+ *   normal:         actions [n, A] = mean + exp(log_std[a]) * N(0, 1)      (ActorCriticNet's Normal, models.py:139-141)
+ *   categorical:    probs [n, A] -> actions [n] int64 by inverse CDF        (A2CNet's Categorical, models.py:105-107)
+ *   ou_noise:       x <- x + theta * (mu - x) + sigma * N(0, 1) on the ONE state of A values all envs share
+ *                   (ddpg_controller.py:29-36; state_in -> state_out, two buffers), actions [n, A] =
+ *                   clip(actor_out + x, low, high) (:93).  A <= 64. */
+int trl_act_epsilon_greedy(const float *q, int64_t n, int32_t A, double eps, uint64_t seed, uint64_t call,
+                           int64_t *actions, void *stream);
+int trl_act_normal(const float *mean, const float *log_std, int64_t n, int32_t A, uint64_t seed, uint64_t call,
+                   float *actions, void *stream);
+int trl_act_categorical(const float *probs, int64_t n, int32_t A, uint64_t seed, uint64_t call, int64_t *actions,
+                        void *stream);
+int trl_act_ou_noise(const float *actor_out, int64_t n, int32_t A, const float *state_in, float *state_out, double theta,
+                     double mu, double sigma, double low, double high, uint64_t seed, uint64_t call, float *actions,
+                     void *stream);
+
 /* ------------------------------------------------------------------ no-allocation entry point
  * trl_ppo_loss for callers that cannot allocate or bring a workspace: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which has no device code at

@@ -186,3 +186,64 @@ def test_act_device_distribution_and_shapes():
   p = PPOController(3, 2, device=dev)
   assert p.act_device(torch.randn(5, 3, device=dev)).shape == (5, 2)
   assert A2CController(4, 3, device=dev).act_device(torch.randn(5, 4, device=dev)).shape == (5,)
+
+
+def test_act_kernels_distributions_and_reproducibility():
+  """f3 as kernels (csrc/trl_act.hip): the reference draws its exploration from numpy's global generator on the
+  host, so parity is distributional.  Checked: exact behaviour where no randomness is involved (eps = 0 is the
+  argmax, sigma = 0 OU is the deterministic decay, clipping), the moments / frequencies of each draw, and that a
+  draw is a function of (seed, call number) alone."""
+  dev = torch.device('cuda:0')
+  g = torch.Generator(device=dev).manual_seed(0)
+  # ---- epsilon-greedy
+  q = torch.randn(50000, 5, device=dev, generator=g)
+  greedy = q.argmax(1)
+  assert torch.equal(F.act_epsilon_greedy(q, 0.0, F.ActRng(1)), greedy)
+  a = F.act_epsilon_greedy(q, 0.3, F.ActRng(1))
+  assert torch.equal(a, F.act_epsilon_greedy(q, 0.3, F.ActRng(1)))                 # same seed, same call number
+  r = F.ActRng(1)
+  r.next()
+  assert not torch.equal(a, F.act_epsilon_greedy(q, 0.3, r))                       # the next call draws afresh
+  keep = float((a == greedy).float().mean())
+  assert abs(keep - (0.7 + 0.3 / 5)) < 0.01
+  off = a[a != greedy]
+  freq = torch.bincount(off, minlength=5).float() / off.numel()
+  assert float((freq - 0.2).abs().max()) < 0.02                                      # uniform over the actions
+  # ---- Normal policy
+  mean = torch.randn(40000, 2, device=dev, generator=g)
+  log_std = torch.tensor([-0.5, 0.3], device=dev)
+  x = F.act_normal(mean, log_std, F.ActRng(7))
+  z = (x - mean) / log_std.exp()
+  assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+  assert abs(float((z[:, 0] * z[:, 1]).mean())) < 0.02                               # the two dimensions are independent
+  assert abs(float((z.abs() < 1.0).float().mean()) - 0.6827) < 0.01
+  assert torch.equal(x, F.act_normal(mean, log_std, F.ActRng(7)))
+  # ---- Categorical policy
+  probs = torch.tensor([[0.1, 0.2, 0.7]], device=dev).repeat(60000, 1)
+  c = F.act_categorical(probs, F.ActRng(3))
+  f = torch.bincount(c, minlength=3).float() / c.numel()
+  assert float((f - torch.tensor([0.1, 0.2, 0.7], device=dev)).abs().max()) < 0.01
+  onehot = torch.eye(4, device=dev)[torch.randint(0, 4, (1000,), device=dev, generator=g)]
+  assert torch.equal(F.act_categorical(onehot, F.ActRng(3)), onehot.argmax(1))       # a certain action is taken
+  # ---- OU noise: one shared state; sigma = 0 is the deterministic decay towards mu, and clipping holds
+  act = torch.zeros(6, 2, device=dev)
+  s0, s1 = torch.tensor([1.0, -2.0], device=dev), torch.empty(2, device=dev)
+  out = F.act_ou_noise(act, s0, s1, 0.15, 0.0, 0.0, -1.0, 1.0, F.ActRng(5))
+  assert torch.allclose(s1, s0 * 0.85) and torch.equal(out, s1.clamp(-1, 1).expand(6, 2))
+  incs = []
+  rng = F.ActRng(5)
+  cur = torch.zeros(2, device=dev)
+  for _ in range(4000):
+    nxt = torch.empty(2, device=dev)
+    F.act_ou_noise(act, cur, nxt, 0.15, 0.0, 0.3, -9.0, 9.0, rng)
+    incs.append((nxt - 0.85 * cur) / 0.3)
+    cur = nxt
+  incs = torch.stack(incs)
+  assert abs(float(incs.mean())) < 0.05 and abs(float(incs.std()) - 1.0) < 0.05
+  # the stationary spread of the process: sigma / sqrt(1 - (1 - theta)^2)
+  # ---- through the controllers
+  from torchrl_amd.contrib.controllers import DDPGController
+  d = DDPGController(3, 2, -2.0, 2.0, device=dev, n_reset_interval=5)
+  for _ in range(7):
+    a = d.act_device(torch.randn(6, 3, device=dev))
+  assert a.shape == (6, 2) and float(a.abs().max()) <= 2.0 and d.noise.step == 2

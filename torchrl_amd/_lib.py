@@ -46,6 +46,12 @@ class AdamArgs(C.Structure):
               ('step', C.c_int64), ('grad_scale', C.c_double), ('clip_value', C.c_double), ('dev_state', C.c_void_p)]
 
 
+class RolloutCols(C.Structure):
+  """mirror of trl_rollout_cols"""
+  _fields_ = [('ncols', C.c_int32), ('width', C.c_int32 * TRL_MAX_COLS), ('block_envs', C.c_int32 * TRL_MAX_COLS),
+              ('group_stride', C.c_int64 * TRL_MAX_COLS), ('dst', C.c_void_p * TRL_MAX_COLS)]
+
+
 class TrlError(RuntimeError):
   pass
 
@@ -73,6 +79,12 @@ PROTOTYPES = {
     'trl_ddpg_critic_loss': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
     'trl_ppo_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64,
                                _vp, _vp, _vp, _vp, _vp, _vp]),
+    'trl_rollout_push': (C.c_int, [_vp, _i64, C.POINTER(RolloutCols), _vp]),
+    'trl_act_epsilon_greedy': (C.c_int, [_vp, _i64, _i32, _f64, C.c_uint64, C.c_uint64, _vp, _vp]),
+    'trl_act_normal': (C.c_int, [_vp, _vp, _i64, _i32, C.c_uint64, C.c_uint64, _vp, _vp]),
+    'trl_act_categorical': (C.c_int, [_vp, _i64, _i32, C.c_uint64, C.c_uint64, _vp, _vp]),
+    'trl_act_ou_noise': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f64, _f64, _f64, _f64, _f64, C.c_uint64, C.c_uint64,
+                                   _vp, _vp]),
     'trl_ppo_loss_static': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64,
                                       _vp, _vp, _vp, _vp, _vp]),
     'trl_normal_logp': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),

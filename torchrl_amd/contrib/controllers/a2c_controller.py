@@ -34,6 +34,7 @@ class A2CController(Controller):
     self.lmbda = lmbda
     self.alpha = alpha
     self.beta = beta
+    self._act_rng = F.ActRng()
 
   def act(self, obs):
     with torch.no_grad():
@@ -42,9 +43,10 @@ class A2CController(Controller):
 
   def act_device(self, obs):
     """act() without the `.cpu().numpy()` host sync: the sampled actions as a device tensor."""
+    need_hip(self.device, 'A2CController.act_device')
     with torch.no_grad():
-      _, dist = self.ac_net(obs_to_tensor(obs, self.device))
-      return dist.sample()
+      _, probs = self.ac_net.heads(obs_to_tensor(obs, self.device))
+      return F.act_categorical(probs, self._act_rng)                      # one launch (csrc/trl_act.hip)
 
   def compute_return(self, obs, action, reward, next_obs, done):  # pylint: disable=unused-argument
     """One env's rollout [T, .] -> returns [T, 1] (a2c_controller.py:29-45)."""

@@ -93,6 +93,7 @@ class DDPGController(Controller):
     self.n_reset_interval = n_reset_interval
     self.huber_delta = huber_delta
     self.noise = OUNoise(action_size)
+    self._act_rng = F.ActRng()
 
   def act(self, obs):
     with torch.no_grad():
@@ -104,22 +105,27 @@ class DDPGController(Controller):
 
   def act_device(self, obs):
     """act() kept on the device (ddpg_controller.py:87-99): the OU state lives in a device tensor
-    and its Gaussian increments come from the device generator; returns a float32 device tensor
+    and its Gaussian increments come from a counter-based generator inside the one act kernel; returns a float32 device tensor
     [n, A].  Same process (theta, sigma schedule, reset interval, clipping) as act(), different
     random stream."""
+    need_hip(self.device, 'DDPGController.act_device')
     obs = obs_to_tensor(obs, self.device)
     noise = self.noise
     with torch.no_grad():
       action = self.actor(obs)
-      if getattr(self, '_ou_dev', None) is None or noise.step == 0:
-        self._ou_dev = torch.full((noise.action_dim,), float(noise.mu), device=self.device)
-      x = self._ou_dev
-      self._ou_dev = x + (noise.theta * (noise.mu - x) + noise.sigma * torch.randn_like(x))
+      if getattr(self, '_ou_dev', None) is None:
+        self._ou_dev = [torch.empty(noise.action_dim, device=self.device) for _ in range(2)]
+        self._ou_cur = 0
+        noise.step = 0
+      if noise.step == 0:                         # fresh or just reset: the state starts at mu (OUNoise.reset)
+        self._ou_dev[self._ou_cur].fill_(float(noise.mu))
+      src, dst = self._ou_dev[self._ou_cur], self._ou_dev[1 - self._ou_cur]
+      # one launch: the OU step on the shared state and the clipped noisy actions (csrc/trl_act.hip)
+      action = F.act_ou_noise(action, src, dst, noise.theta, noise.mu, noise.sigma, self.action_low, self.action_high,
+                              self._act_rng)
+      self._ou_cur = 1 - self._ou_cur
       noise.sigma = noise.max_sigma - (noise.max_sigma - noise.min_sigma) * min(1.0, noise.step / noise.decay_period)
       noise.step += 1
-      low = torch.as_tensor(self.action_low, dtype=torch.float32, device=self.device)
-      high = torch.as_tensor(self.action_high, dtype=torch.float32, device=self.device)
-      action = torch.minimum(torch.maximum(action + self._ou_dev, low), high)
     if noise.step % self.n_reset_interval == 0:
       noise.reset()
     return action

@@ -73,6 +73,7 @@ class DQNController(Controller):
     self.huber_delta = huber_delta             # None = the reference's MSE
     self.eps = ExpDecaySchedule(start=eps_max, end=eps_min, num_steps=n_eps_anneal)
     self._steps = 0
+    self._act_rng = F.ActRng()
 
   def act(self, obs):
     with torch.no_grad():
@@ -82,16 +83,14 @@ class DQNController(Controller):
 
   def act_device(self, obs):
     """act() without the device -> host round trip (dqn_controller.py:57-59): epsilon-greedy drawn
-    with the device generator, actions returned as an int64 device tensor [n].  Same action
+    by one HIP kernel from a counter-based generator (Philox), actions returned as an int64 device tensor [n].  Same action
     distribution as act() (greedy w.p. 1 - eps + eps/A, any other action w.p. eps/A); the draws
     themselves differ because the reference uses numpy's global generator on the host."""
+    need_hip(self.device, 'DQNController.act_device')
     obs = obs_to_tensor(obs, self.device)
     with torch.no_grad():
-      greedy = self.q_net(obs).argmax(dim=-1)
-      eps = self.eps.value
-      explore = torch.rand(greedy.shape, device=self.device) < eps
-      uniform = torch.randint(0, self.action_size, greedy.shape, device=self.device)
-      return torch.where(explore, uniform, greedy)
+      q = self.q_net(obs)
+    return F.act_epsilon_greedy(q, self.eps.value, self._act_rng)      # one launch (csrc/trl_act.hip)
 
   def _learn_body(self, obs, action, reward, next_obs, done):
     if self._fused is not None and self._fused.usable(obs):

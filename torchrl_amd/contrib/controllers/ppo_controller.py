@@ -41,6 +41,7 @@ class PPOController(Controller):
     self.beta = beta
     self.clip_ratio = clip_ratio
     self.max_grad_norm = max_grad_norm
+    self._act_rng = F.ActRng()
 
   def act(self, obs):
     with torch.no_grad():
@@ -49,9 +50,14 @@ class PPOController(Controller):
 
   def act_device(self, obs):
     """act() without the `.cpu().numpy()` host sync: the sampled actions as a device tensor."""
+    need_hip(self.device, 'PPOController.act_device')
+    obs = obs_to_tensor(obs, self.device)
     with torch.no_grad():
-      _, dist = self.ac_net(obs_to_tensor(obs, self.device))
-      return dist.sample()
+      if self._fused is not None and self._fused.usable(obs):
+        _, mean, _ = self._fused.forward(obs, want_value=False)         # forward-only kernel, mean alone
+      else:
+        mean = self.ac_net.actor(obs)
+      return F.act_normal(mean, self.ac_net.log_std, self._act_rng)      # one launch (csrc/trl_act.hip)
 
   def compute_return(self, obs, action, reward, next_obs, done):
     """One env's rollout [T, .] -> (returns [T, 1], log_probs [T, A], values [T, 1])

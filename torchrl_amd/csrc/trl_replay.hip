@@ -574,27 +574,6 @@ constexpr int SAMP_MAX_B = 4096;
 constexpr int SAMP_SLOTS = 2 * SAMP_MAX_B;     // open addressing, load factor <= 0.5
 constexpr uint32_t SAMP_EMPTY = 0xffffffffu;
 
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  c[1] = (uint32_t)p1;
-  c[3] = (uint32_t)p0;
-  c[0] = n0;
-  c[2] = n2;
-}
-
-__device__ __forceinline__ uint64_t philox64(uint64_t seed, uint64_t call, uint32_t pos, uint32_t attempt) {
-  uint32_t c[4] = {(uint32_t)call, (uint32_t)(call >> 32), pos, attempt};
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return ((uint64_t)c[0] << 32) | c[1];
-}
-
 __global__ __launch_bounds__(1024) void k_sample_distinct(int64_t n, int B, uint64_t seed,
                                                           unsigned long long *__restrict__ call_counter,
                                                           int64_t *__restrict__ out) {

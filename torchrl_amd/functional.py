@@ -149,6 +149,79 @@ def from_blocked(x):
   return x.permute(perm).reshape((T, G * E) + rest).contiguous()
 
 
+# ------------------------------------------------------------------------------ exploration on the device
+class ActRng:
+  """Seed + call counter of a controller's on-device exploration (csrc/trl_act.hip: Philox keyed by the seed,
+  counter = (call number, row)); the seed defaults to torch.initial_seed() at the first draw."""
+
+  def __init__(self, seed=None):
+    self.seed, self.calls = seed, 0
+
+  def next(self):
+    if self.seed is None:
+      self.seed = int(torch.initial_seed())
+    self.calls += 1
+    return self.seed & (2 ** 64 - 1), self.calls - 1
+
+
+def act_epsilon_greedy(q, eps, rng):
+  """q [n, A] float32 -> int64 actions [n]: greedy w.p. 1 - eps + eps / A, any other action w.p. eps / A
+  (the categorical of dqn_controller.py:16-22), one launch, no host round trip."""
+  q = _f32c(q, 'q')
+  n, A = q.shape
+  out = torch.empty(n, dtype=torch.int64, device=q.device)
+  seed, call = rng.next()
+  with torch.cuda.device(q.device):
+    _lib.check(_lib.lib().trl_act_epsilon_greedy(q.data_ptr(), n, A, float(eps), seed, call, out.data_ptr(),
+                                                 _lib.stream_ptr(q.device)))
+  return out
+
+
+def act_normal(mean, log_std, rng):
+  """mean [n, A], log_std [A] -> mean + exp(log_std) * N(0, 1) (ActorCriticNet's Normal(...).sample())."""
+  mean = _f32c(mean, 'mean')
+  n, A = mean.shape
+  log_std = _f32c(log_std, 'log_std').view(-1)
+  if log_std.numel() != A:
+    raise ValueError('act_normal: log_std must hold %d values' % A)
+  out = torch.empty_like(mean)
+  seed, call = rng.next()
+  with torch.cuda.device(mean.device):
+    _lib.check(_lib.lib().trl_act_normal(mean.data_ptr(), log_std.data_ptr(), n, A, seed, call, out.data_ptr(),
+                                         _lib.stream_ptr(mean.device)))
+  return out
+
+
+def act_categorical(probs, rng):
+  """probs [n, A] -> int64 actions [n] ~ Categorical(probs) (A2CNet's policy head)."""
+  probs = _f32c(probs, 'probs')
+  n, A = probs.shape
+  out = torch.empty(n, dtype=torch.int64, device=probs.device)
+  seed, call = rng.next()
+  with torch.cuda.device(probs.device):
+    _lib.check(_lib.lib().trl_act_categorical(probs.data_ptr(), n, A, seed, call, out.data_ptr(),
+                                              _lib.stream_ptr(probs.device)))
+  return out
+
+
+def act_ou_noise(actor_out, state_in, state_out, theta, mu, sigma, low, high, rng):
+  """One Ornstein-Uhlenbeck step of the shared [A] state (state_in -> state_out) and
+  clip(actor_out + state, low, high) (ddpg_controller.py:29-36, 93), one launch."""
+  a = _f32c(actor_out, 'actor_out')
+  n, A = a.shape
+  for t, nm in ((state_in, 'state_in'), (state_out, 'state_out')):
+    _lib.require_device(t, nm)
+    if t.dtype != torch.float32 or t.numel() != A or not t.is_contiguous():
+      raise ValueError('act_ou_noise: %s must be a contiguous float32 [%d]' % (nm, A))
+  out = torch.empty_like(a)
+  seed, call = rng.next()
+  with torch.cuda.device(a.device):
+    _lib.check(_lib.lib().trl_act_ou_noise(a.data_ptr(), n, A, state_in.data_ptr(), state_out.data_ptr(), float(theta),
+                                           float(mu), float(sigma), float(low), float(high), seed, call, out.data_ptr(),
+                                           _lib.stream_ptr(a.device)))
+  return out
+
+
 # ------------------------------------------------------------------------------ TD losses
 class _TdLoss(torch.autograd.Function):
   @staticmethod

@@ -4,7 +4,7 @@ The reference keeps one TransitionTupleDataset per env, appends one transition p
 (`torch.cat` of the whole column each time), and at train time walks the envs in Python:
 `buffer[:]`, `compute_return`, `torch.cat` over envs (examples/ppo.py:28-35, 43-68; a2c.py the
 same).  Here one env step over all N envs is ONE row of preallocated `[T, N, .]` device
-tensors (a single small H2D copy per column), the return/advantage pass is one batched call,
+tensors (one scatter launch reading the packed transitions from pinned memory), the return/advantage pass is one batched call,
 and minibatches come out in the reference's order: env-major, sequential, last partial batch
 kept (`DataLoader(ds, batch_size)` at examples/ppo.py:68).
 
@@ -16,6 +16,8 @@ consecutive slices of that order (a group's steps, E envs interleaved) -- the sa
 epoch as the reference's env-major order, cut into minibatches differently; use the default layout
 with `env_major()` where the reference's exact minibatch composition matters.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -69,7 +71,12 @@ class RolloutBuffer:
       self._last_next_obs = torch.empty((self.n_envs, obs.shape[1]), dtype=torch.float32, device=self._device)
       self._pin = [torch.empty(row.shape, dtype=torch.float32).pin_memory() for _ in range(8)]
       self._pin_ev = [None] * 8
-      self._stage = torch.empty(row.shape, dtype=torch.float32, device=self._device)
+      cols = self._push_cols = _lib.RolloutCols()
+      cols.ncols = 5
+      for i, w in enumerate(self._widths + [obs.shape[1]]):
+        cols.width[i] = w
+      cols.dst[4] = self._last_next_obs.data_ptr()           # next_obs of the step: dense [N, O], overwritten every step
+      cols.block_envs[4], cols.group_stride[4] = 1, obs.shape[1]
     if self._t == self._cap:
       new = self._alloc(self._widths, 2 * self._cap)
       for n, o in zip(new, self._cols):
@@ -79,18 +86,23 @@ class RolloutBuffer:
     if self._pin_ev[slot] is not None:
       self._pin_ev[slot].synchronize()
     self._pin[slot].copy_(torch.from_numpy(row))
-    self._stage.copy_(self._pin[slot], non_blocking=True)       # one H2D per env step
+    # ONE launch: the push kernel reads the packed rows straight out of pinned memory and scatters every
+    # column to its place at step t (csrc/trl_act.hip; no DMA-engine copy, no per-column slice copies)
+    cols = self._push_cols
+    E = self.block_envs
+    for i, (col, w) in enumerate(zip(self._cols, self._widths)):
+      if self.layout == 'blocked':
+        cols.dst[i] = col.data_ptr() + 4 * self._t * E * w
+        cols.block_envs[i], cols.group_stride[i] = E, self._cap * E * w
+      else:
+        cols.dst[i] = col.data_ptr() + 4 * self._t * self.n_envs * w
+        cols.block_envs[i], cols.group_stride[i] = 1, w
+    with torch.cuda.device(self._device):
+      _lib.check(_lib.lib().trl_rollout_push(self._pin[slot].data_ptr(), self.n_envs, C.byref(cols),
+                                             _lib.stream_ptr(self._device)))
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(self._device))
     self._pin_ev[slot] = ev
-    off = 0
-    for col, w in zip(self._cols, self._widths):
-      if self.layout == 'blocked':
-        col[:, self._t].copy_(self._stage[:, off:off + w].view(-1, self.block_envs, w))
-      else:
-        col[self._t].copy_(self._stage[:, off:off + w])
-      off += w
-    self._last_next_obs.copy_(self._stage[:, off:])
     self._t += 1
 
   def truncate(self):
