@@ -721,6 +721,24 @@ def main():
           gather_roofline(dev, args.kernel_iters, 200_000, 1024, atari=True),
           gather_roofline(dev, args.kernel_iters, 200_000, 256, atari=True),
       ]
+    if args.workload == 'ppo' and not args.no_extras:
+      # BASELINE configs 3 and 4 (and A2C on the reference's own 256-wide net) in the same driver-run line: each at its
+      # own default steps / minibatch / capacity (`bench.py --workload <name>` prints the same object on its own)
+      import copy
+      res['other_workloads'] = []
+      for wl, hidden in (('ddpg', None), ('dqn_atari', None), ('a2c', '256')):
+        a2 = copy.copy(args)
+        a2.workload, a2.steps, a2.warmup, a2.minibatch, a2.capacity = wl, None, None, None, None
+        a2.use_graph = False
+        if hidden:
+          a2.hidden = hidden
+        torch.cuda.empty_cache()
+        try:
+          r2, _ = bench_a2c(a2, rank, world, dev) if wl == 'a2c' else bench_offpolicy(a2, rank, world, dev, atari=wl == 'dqn_atari')
+          res['other_workloads'].append({k: r2[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'roofline')
+                                         if k in r2})
+        except Exception as e:  # noqa: BLE001  (an extra must not take the headline line down)
+          res['other_workloads'].append({'workload': wl, 'error': str(e)[:300]})
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline_ppo(info) if args.workload == 'ppo' else cpu_baseline_offpolicy(info)
   if dist.is_initialized():
