@@ -20,6 +20,8 @@ DEV = 'cuda:0'
 CASES = [(3, 1, (64, 64), 65536), (3, 1, (64, 64), 4097), (4, 2, (64, 64), 9000), (17, 2, (48, 33), 5000),
          (40, 1, (64, 64), 3000), (64, 2, (64, 64), 2048), (3, 1, (64,), 8192), (5, 4, (64,), 7001),
          (33, 3, (20,), 300), (3, 1, (64, 64), 256),
+         # two hidden layers over <= 4 observations at >= 32768 rows: the eight-wave variant (two waves per SIMD)
+         (3, 1, (64, 64), 40001), (4, 2, (64, 64), 33000), (2, 2, (48, 33), 50000), (1, 1, (64, 20), 32768),
          # one hidden layer wider than 64 over <= 4 observations (ppo_controller.py:14 builds 256): hidden blocks
          (3, 1, (256,), 65536), (3, 1, (256,), 4097), (4, 1, (200,), 3000), (4, 2, (128,), 5000), (2, 2, (100,), 900),
          (3, 1, (96,), 1000), (1, 1, (129,), 2048), (4, 2, (256,), 5000), (3, 2, (200,), 999)]

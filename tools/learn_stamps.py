@@ -13,27 +13,28 @@ from torchrl_amd import functional as F  # noqa: E402
 from torchrl_amd.contrib.controllers import PPOController  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+NW = int(os.environ.get('TRL_LEARN_NW', '8')) if B >= 32768 else 4     # waves per workgroup of the variant taken
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
 ctl = PPOController(3, 1, device=dev, hidden=(64, 64))
 obs, act = torch.randn(B, 3, device=dev), torch.randn(B, 1, device=dev)
 ret, adv, old = torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev) - 1
 f = ctl._fused
-for _ in range(3000):          # >= 2 s of back-to-back launches
+for _ in range(int(os.environ.get('ITERS', 3000))):          # >= 2 s of back-to-back launches
   f(obs, act, ret, old, adv, 0.2, 0.5, 1e-3)
 torch.cuda.synchronize()
-ws = F._lin_ws[0]
+ws = f._ws.buf.view(torch.uint8)
 np_c, np_a = 4481, 4481
 pstride = (max(np_c, np_a) + 8 + 3) // 4 * 4
-nwg = min(128, (B + 127) // 128)
-raw = ws[2 * 128 * pstride * 4:2 * 128 * pstride * 4 + 2 * nwg * 4 * 64].cpu().numpy().view(np.uint64)
-st = raw.reshape(2 * nwg * 4, 8).astype(np.float64)
+nwg = min(128, (B + 32 * NW - 1) // (32 * NW))
+raw = ws[2 * 128 * pstride * 4:2 * 128 * pstride * 4 + 2 * nwg * NW * 64].cpu().numpy().view(np.uint64)
+st = raw.reshape(2 * nwg * NW, 8).astype(np.float64)
 clk, rt = st[:, 0::2], st[:, 1::2]
 for i, name in enumerate(('staging', 'strip loop', 'partials out')):
   dc, dr = clk[:, i + 1] - clk[:, i], rt[:, i + 1] - rt[:, i]
   print('%-13s median %8.0f shader cycles  %6.2f us' % (name, np.median(dc), np.median(dr) / 100.0))
 for net, name in enumerate(('critic', 'actor')):      # rows [net * nwg * 4, (net + 1) * nwg * 4) are that network's waves
-  sl = slice(net * nwg * 4, (net + 1) * nwg * 4)
+  sl = slice(net * nwg * NW, (net + 1) * nwg * NW)
   dr = rt[sl, 2] - rt[sl, 1]
   print('strip loop, %-6s waves: median %7.2f us  max %7.2f us' % (name, np.median(dr) / 100.0, dr.max() / 100.0))
 dc, dr = clk[:, 3] - clk[:, 0], rt[:, 3] - rt[:, 0]
@@ -43,10 +44,10 @@ print('first entry -> last exit over all waves: %.2f us' % ((rt[:, 3].max() - rt
 print('entry spread: %.2f us' % ((rt[:, 0].max() - rt[:, 0].min()) / 100.0))
 dc, dr = clk[:, 2] - clk[:, 1], rt[:, 2] - rt[:, 1]
 print('loop clock %.2f GHz' % (np.median(dc / dr) * 0.1))
-off = 2 * 128 * pstride * 4 + 2 * 128 * 4 * 64
-ph = ws[off:off + 2 * nwg * 4 * 128].cpu().numpy().view(np.uint64)
-ph = ph.reshape(2 * nwg * 4, 16).astype(np.float64)
-nst = (B + 31) // 32 / (nwg * 4)
+off = 2 * 128 * pstride * 4 + 2 * 128 * 8 * 64
+ph = ws[off:off + 2 * nwg * NW * 128].cpu().numpy().view(np.uint64)
+ph = ph.reshape(2 * nwg * NW, 16).astype(np.float64)
+nst = (B + 31) // 32 / (nwg * NW)
 names = {5: 'loop top -> inputs in registers', 6: 'x tile write + fence', 7: 'layer 0 forward + relu', 8: 'layer 1 forward + relu',
          0: 'last layer forward', 1: 'loss + last layer backward', 2: 'layer 1 backward (tiles, dW1, g0, mask)',
          9: 'layer 0 backward: db0, tile, fence', 3: 'layer 0 backward: dW0 MFMAs'}

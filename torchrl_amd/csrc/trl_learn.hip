@@ -85,7 +85,7 @@ constexpr float F32_LOWEST = -3.4028234663852886e+38f;
   do {                                                                                                  \
     if (lane == 0) {                                                                                    \
       unsigned long long *sp = (unsigned long long *)(P.ws + 2ll * 128 * P.pstride) +                   \
-                               (((int64_t)net * gridDim.x + blockIdx.x) * 4 + wave) * 8;                \
+                               (((int64_t)net * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 8;                \
       sp[2 * (i)] = __builtin_amdgcn_s_memtime();                                                       \
       sp[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                                               \
     }                                                                                                   \
@@ -101,8 +101,8 @@ constexpr float F32_LOWEST = -3.4028234663852886e+38f;
 #define PH_OUT                                                                                          \
   do {                                                                                                  \
     if (lane == 0) {                                                                                    \
-      unsigned long long *sp = (unsigned long long *)(P.ws + 2ll * 128 * P.pstride) + 2 * 128 * 4 * 8 + \
-                               (((int64_t)net * gridDim.x + blockIdx.x) * 4 + wave) * 16;               \
+      unsigned long long *sp = (unsigned long long *)(P.ws + 2ll * 128 * P.pstride) + 2 * 128 * 8 * 8 + \
+                               (((int64_t)net * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 16;               \
       for (int k = 0; k < 12; ++k) sp[k] = ph_acc[k];                                                    \
     }                                                                                                   \
   } while (0)
@@ -137,10 +137,19 @@ __device__ __forceinline__ void relu2(f32x16 (&h)[2]) {
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float y;
-      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(h[nb][r]));   // one instruction (fmaxf adds a canonicalize)
-      h[nb][r] = y;
+      // max(x, 0) as ONE instruction the compiler can see: a signed-integer max on the bit pattern (negative floats,
+      // -0 included, are negative integers).  fmaxf adds a canonicalize; an inline-asm v_max_f32 is opaque to the
+      // hazard recognizer, which then leaves out the wait states between an MFMA and this read of its result.
+      const float x = h[nb][r];      // (a copy: bit-casting the vector-element lvalue itself reads element 0)
+      const int b = __float_as_int(x);
+      h[nb][r] = __int_as_float(b > 0 ? b : 0);
     }
+}
+
+// a wave-uniform float moved to a scalar register (the compiler keeps what the VALU computed in a vector register,
+// live across the whole strip loop)
+__device__ __forceinline__ float uni(float x) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)p; }
@@ -295,47 +304,75 @@ __device__ __forceinline__ void fwd_last(float (&out)[NO], const f32x16 (&hl)[2]
   fwd_last_finish<NO>(out, p, sBL);
 }
 
+// layer 1 backward, input side: t^T[k][row] = sum_n W1[n][k] g^T[n][row]; A = W1^T[k = kb*32 + r32][n], four n per
+// read, one group ahead
+__device__ __forceinline__ void bwd_dx1(f32x16 (&t)[2], const f32x16 (&g)[2], const float *sW1T, int half, int r32) {
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[kb][r] = 0.f;
+  const float *wt = sW1T + r32 * LDW + 4 * half;
+  float4 a0 = ld4(wt), a1 = ld4(wt + 32 * LDW);
+#pragma unroll
+  for (int gq = 0; gq < 8; ++gq) {
+    const int nb = gq >> 2, q = gq & 3;
+    float4 n0 = a0, n1 = a1;
+    if (gq + 1 < 8) {
+      const int c = ((gq + 1) >> 2) * 32 + 8 * ((gq + 1) & 3);
+      n0 = ld4(wt + c);
+      n1 = ld4(wt + 32 * LDW + c);
+    }
+    issue_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t[0] = MFMA(f4(a0, i), g[nb][4 * q + i], t[0]);
+      t[1] = MFMA(f4(a1, i), g[nb][4 * q + i], t[1]);
+    }
+    a0 = n0; a1 = n1;
+  }
+}
+
 // weights of one network, zero-padded, into LDS, once per workgroup.  Loads first, stores after:
 // every load of a tile is in flight at once (a load -> store loop pays the L2 latency per iteration)
-template <int D, int LDW0, int NO, bool WITH_T, int HB = 1>
+template <int D, int LDW0, int NO, bool WITH_T, int HB = 1, int NT = 256>
 __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, float *sW1, float *sW1T, float *sWL,
                                               float *sB, int tid) {
   const int K0 = a.dims[0], H1 = a.dims[1], HL = a.dims[D - 1], NOr = a.dims[D];
   {
-    constexpr int N0 = (HB * 64 * LDW0 + 255) / 256;
+    constexpr int N0 = (HB * 64 * LDW0 + NT - 1) / NT;
     float v[N0];
 #pragma unroll
     for (int i = 0; i < N0; ++i) {
-      const int e = tid + 256 * i, n = e / LDW0, k = e % LDW0;      // n = q * 64 + local feature
+      const int e = tid + NT * i, n = e / LDW0, k = e % LDW0;      // n = q * 64 + local feature
       v[i] = (n < H1 && k < K0 && e < HB * 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < N0; ++i)
-      if (tid + 256 * i < HB * 64 * LDW0) sW0[tid + 256 * i] = v[i];
+      if (tid + NT * i < HB * 64 * LDW0) sW0[tid + NT * i] = v[i];
   }
   if (D == 3) {
     const int H2 = a.dims[2];
-    constexpr int N1 = 64 * 64 / 256;
+    constexpr int N1 = 64 * 64 / NT;
     float v[N1];
 #pragma unroll
     for (int i = 0; i < N1; ++i) {
-      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
+      const int e = tid + NT * i, n = e >> 6, k = e & 63;
       v[i] = (n < H2 && k < H1) ? a.w[1][n * H1 + k] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < N1; ++i) {
-      const int e = tid + 256 * i, n = e >> 6, k = e & 63;
+      const int e = tid + NT * i, n = e >> 6, k = e & 63;
       sW1[n * LDW + k] = v[i];
       if (WITH_T) sW1T[k * LDW + n] = v[i];
     }
   }
   // last layer: block q of the hidden features at sWL + q * NO * 64, [n][64] each
-  for (int e = tid; e < HB * NO * 64; e += 256) {
+  for (int e = tid; e < HB * NO * 64; e += NT) {
     const int q = e / (NO * 64), r = e - q * NO * 64, n = r >> 6, k = q * 64 + (r & 63);
     sWL[e] = (n < NOr && k < HL) ? a.w[D - 1][n * HL + k] : 0.f;
   }
   // biases: b0 (HB * 64), b1 (64), bL (4)
-  for (int e = tid; e < HB * 64 + 64 + 4; e += 256) {
+  for (int e = tid; e < HB * 64 + 64 + 4; e += NT) {
     float v = 0.f;
     if (e < HB * 64) v = e < H1 ? a.b[0][e] : 0.f;
     else if (e < HB * 64 + 64) v = (D == 3 && e - HB * 64 < a.dims[2]) ? a.b[1][e - HB * 64] : 0.f;
@@ -351,29 +388,52 @@ __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, floa
 // fan-in of at most 4, where a hidden layer of up to 256 units (the reference's own ActorCriticNet / A2CNet
 // width, ppo_controller.py:14) is walked block by block inside the wave: that shape has no square product at
 // all, only layer 0, the last layer's dot product and their transposes, each per block.
-template <int D, int KB0, int NO, bool XP, int HB = 1>
-__global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
+// NW = wavefronts per workgroup.  4: one wave per SIMD with the whole register file.  8 (two hidden layers over a
+// fan-in of at most 4): two waves per SIMD at 256 registers each, so that one wave's VALU / LDS stretches (ReLU
+// masks, last layer, loss, the transposes) run under the other's MFMAs -- a single wave cannot overlap them with its
+// own dependent MFMA chain.  To fit eight waves' tiles in LDS the x tile shrinks to the 4 rows a fan-in <= 4 uses,
+// and the h1^T tile of the layer-1 weight gradient to one 32-feature half, written and consumed twice.
+template <int D, int KB0, int NO, bool XP, int HB = 1, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
   static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
-  constexpr int LDW0 = 32 * KB0 + 1;
-  constexpr int XT = 32 * KB0 * LDT + 4;             // floats of the x tile (+ a dummy slot for idle prefetch lanes)
+  static_assert(NW == 4 || (NW == 8 && D == 3 && KB0 == 1 && XP && HB == 1), "eight waves: two hidden layers, fan-in <= 4");
+  constexpr int NT = 64 * NW;
+  constexpr bool W0C = NW == 8;                      // layer-0 weight gradient on the VALU, known at compile time
+  constexpr bool HT = NW == 8;                       // half h1^T tile
+  constexpr bool STG = NW == 8;                      // inputs of the next strip wait in LDS, not in registers
+  constexpr int LDW0 = W0C ? 5 : 32 * KB0 + 1;
+  constexpr int XROWS = W0C ? 4 : 32 * KB0;
+  constexpr int XT = XROWS * LDT + 4;                // floats of the x tile (+ a dummy slot for idle prefetch lanes)
   // WLV: 4 hidden blocks x 2 outputs.  The last layer's weight gradient is accumulated per feature from LDS tiles
   // (rows_dwl) instead of per lane in 256 registers; the activation tile and the output-gradient rows it reads
   // take the place D == 3 uses for h1^T (+ 4 rows)
   constexpr bool WLV = HB * NO > 4;
-  constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0) + (WLV ? 64 * LDT + 4 * LDT : 0);   // per-wave scratch
+  constexpr bool DWF = NW == 8;                      // last-layer weight gradient per feature, through the g tile
+  constexpr int GOR = WLV ? 4 : (DWF ? NO : 0);      // rows of the output-gradient tile
+  constexpr int SIN = STG ? XT + (1 + 2 * NO) * 32 : 0;   // second x tile + one 32-row slot per loss input
+  constexpr int WT = XT + 64 * LDT + (D == 3 ? (HT ? 32 : 64) * LDT : 0) + (WLV ? 64 * LDT : 0) + GOR * LDT + SIN;   // per-wave scratch
   constexpr int WTP = (WT + 3) & ~3;
-  __shared__ __align__(16) float sW0[HB * 64 * LDW0];
-  __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];    // W1[n][k]
-  __shared__ __align__(16) float sW1T[D == 3 ? 64 * LDW : 4];   // W1^T: [k][n], the backward's A operand
-  __shared__ __align__(16) float sWL[HB * NO * 64];
-  __shared__ __align__(16) float sB[HB * 64 + 64 + 4];   // b0 (HB blocks), b1 (padded with zeros), bL
-  __shared__ __align__(16) float sT[4 * WTP];
-  static_assert(WTP >= 64 * 32 * KB0 && (D == 2 || WTP >= 64 * 64) && 4 * WTP >= 4 * 12 * 64 + 64,
+  // One LDS array, carved by hand with the weights first: everything every strip reads (biases, last layer, W0, W1,
+  // W1^T) then sits below 64 KB, within reach of a ds instruction's 16-bit offset from a lane's base register.
+  // As separate arrays the compiler placed them behind the 120+ KB of tiles and kept one address register per read.
+  constexpr int OFF_B = 0;                                          // b0 (HB blocks), b1 (padded with zeros), bL
+  constexpr int OFF_WL = OFF_B + ((HB * 64 + 64 + 4 + 3) & ~3);
+  constexpr int OFF_W0 = OFF_WL + HB * NO * 64;
+  constexpr int OFF_W1 = OFF_W0 + ((HB * 64 * LDW0 + 3) & ~3);      // W1[n][k]
+  constexpr int OFF_W1T = OFF_W1 + (D == 3 ? 64 * LDW : 0);         // W1^T: [k][n], the backward's A operand
+  constexpr int OFF_T = OFF_W1T + (D == 3 ? 64 * LDW : 0);
+  __shared__ __align__(16) float smem[OFF_T + NW * WTP];
+  float *const sB = smem + OFF_B, *const sWL = smem + OFF_WL, *const sW0 = smem + OFF_W0, *const sW1 = smem + OFF_W1,
+               *const sW1T = smem + OFF_W1T, *const sT = smem + OFF_T;
+  static_assert(WTP >= 32 * 32 * KB0 && (D == 2 || WTP >= 32 * 64) && NW * WTP >= NW * 12 * 64 + NW * 16,
                 "the end-of-kernel reduction re-uses the per-wave scratch");
 
   const int net = blockIdx.y;
   const NetArgs &a = P.net[net];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  // (the wave index as a scalar: the strip number, the row base and every input address derived from it then stay
+  // in scalar registers, and only the lane's own 32-bit offsets take vector registers)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5,
+            r32 = lane & 31;
   const int K0 = a.dims[0], H1 = a.dims[1];
   const int HL = a.dims[D - 1];      // fan-in of the last layer
   const int NOr = a.dims[D];         // its actual fan-out
@@ -381,17 +441,22 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int A = P.A;
 
   STAMP(0);
-  stage_weights<D, LDW0, NO, true, HB>(a, sW0, sW1, sW1T, sWL, sB, tid);
+  stage_weights<D, LDW0, NO, true, HB, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
   float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
   float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
   float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T; (WLV) the block's activations
-  float *sGo = sH + 64 * LDT;       // [4][LDT]       (WLV) gradient w.r.t. the outputs, one row per output
+  float *sGo = sX + WT - SIN - GOR * LDT;   // [GOR][LDT]  (WLV, DWF) gradient w.r.t. the outputs, one row per output
+  float *sX2 = sX + WT - SIN;       // (STG) the other x tile, then the loss inputs [1 + 2 NO][32]
+  float *sIn = sX2 + XT;
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;   // rows >= K0 stay zero for good
+  if (STG)
+    for (int e = lane; e < XT; e += 64) sX2[e] = 0.f;
   __syncthreads();
   STAMP(1);
 
   // ---- per-wave persistent state
-  f32x16 accW0[2][KB0];
+  constexpr int KA0 = W0C ? 0 : KB0;     // MFMA accumulators of dW0 (none when it runs on the VALU for certain)
+  f32x16 accW0[2][KA0 ? KA0 : 1];
   f32x16 accW1[2][2];
   // NBQ: hidden blocks whose backward this workgroup runs.  4 blocks x 2 outputs would need 256 registers for
   // the last layer's gradient accumulators alone, so that case is launched with gridDim.z = 2: every z runs
@@ -405,9 +470,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   float dwlv[NBQ][NO];          // WLV: last-layer weight gradient of feature `lane` of block q
   float vdb0[NBQ], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
   // fan-in <= 4: dW0[lane][k] accumulates per lane on the VALU (row_sum32_dw4) instead of in accW0
-  const bool w0v = HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
+  const bool w0v = W0C || HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
   float dw0v[NBQ][4];
-  f32x16 dWL[WLV ? 1 : NBQ][NO][2];
+  f32x16 dWL[WLV || DWF ? 1 : NBQ][NO][2];
 #pragma unroll
   for (int qb = 0; qb < NBQ; ++qb) {
 #pragma unroll
@@ -420,7 +485,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
-    for (int kb = 0; kb < KB0; ++kb)
+    for (int kb = 0; kb < KA0; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accW0[nb][kb][r] = 0.f;
 #pragma unroll
@@ -432,7 +497,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   for (int n = 0; n < NO; ++n) {
     dbL[n] = 0.f;
 #pragma unroll
-    for (int qb = 0; qb < (WLV ? 1 : NBQ); ++qb)
+    for (int qb = 0; qb < (WLV || DWF ? 1 : NBQ); ++qb)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -447,13 +512,13 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     den[n] = var[n] = 1.f; logsig[n] = 0.f;
     if (net == 1 && P.kind == KIND_PPO && n < A) {
       const float sigma = expf(P.log_std[n]);   // self.log_std.exp()
-      var[n] = sigma * sigma;                   // scale ** 2
-      logsig[n] = logf(sigma);                  // scale.log()
-      den[n] = 2.0f * var[n];
+      var[n] = uni(sigma * sigma);              // scale ** 2
+      logsig[n] = uni(logf(sigma));             // scale.log()
+      den[n] = uni(2.0f * (sigma * sigma));
     }
   }
-  const float invB = 1.0f / (float)B;
-  const float gmin = -(1.0f / (float)(B * A));   // d loss / d min(surr1, surr2) element
+  const float invB = uni(1.0f / (float)B);
+  const float gmin = uni(-(1.0f / (float)(B * A)));   // d loss / d min(surr1, surr2) element
   const int q64 = 64 / K0, m64 = 64 % K0;
   const int ksteps0 = (K0 + 1) >> 1;
 
@@ -463,7 +528,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // The fetch is branch-free -- clamped addresses, idle lanes write a dummy LDS slot -- so that
   // the loads of strip i+1 stay in flight across strip i (a load under a branch makes the
   // compiler drain the vector-memory counter at the next join).
-  constexpr int XPF = 6;
+  constexpr int XPF = W0C ? 2 : 6;     // 32 rows x fan-in <= 4: at most 128 elements
   const int nelem = 32 * K0;
   int xoff[XPF];
   {
@@ -490,29 +555,48 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
   for (int j = 0; j < XPF; ++j) xr[j] = 0.f;
   const int64_t nstrips = (B + 31) >> 5;
-  auto fetch = [&](int64_t strip) {
+  auto fetch = [&](int64_t strip) {      // (strip is wave-uniform: scalar bases, 32-bit lane offsets)
     strip = strip < nstrips ? strip : nstrips - 1;
     const int64_t row0 = strip << 5;
-    const int64_t row = row0 + r32;
-    const int64_t rowc = row < B ? row : B - 1;
+    const int64_t left = B - row0;                    // rows from row0 to the end (>= 1)
+    const int rows = (int)(left < 32 ? left : 32);
+    const int rl = r32 < rows ? r32 : rows - 1;       // the lane's row within the strip, clamped to the last valid one
     if (XP) {
       const float *base = P.obs + row0 * K0;
-      const int64_t avail = (B - row0) * K0;          // elements before the end of obs (>= K0)
-      const int last = (int)(avail < nelem ? avail : nelem) - 1;
+      const int last = rows * K0 - 1;                 // last element of the strip's rows
 #pragma unroll
       for (int j = 0; j < XPF; ++j) {
         const int e = lane + 64 * j;
         xr[j] = base[e < last ? e : last];
       }
     }
-    p_in0 = in0[rowc];
+    p_in0 = (in0 + row0)[rl];
 #pragma unroll
-    for (int n = 0; n < NO; ++n) { p_act[n] = in_act[n][rowc * astr]; p_olp[n] = in_olp[n][rowc * astr]; }
+    for (int n = 0; n < NO; ++n) {
+      p_act[n] = (in_act[n] + row0 * astr)[rl * astr];
+      p_olp[n] = (in_olp[n] + row0 * astr)[rl * astr];
+    }
   };
 
-  const int64_t sstride = (int64_t)gridDim.x * 4;
-  int64_t strip = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t sstride = (int64_t)gridDim.x * NW;
+  int64_t strip = (int64_t)blockIdx.x * NW + wave;
   fetch(strip);
+  // STG (eight waves, 256 registers): values fetched a strip ahead would sit in registers across the whole strip
+  // body, where the compiler spills them (and waits for the load to do so).  They are parked in LDS instead, as
+  // soon as the forward's MFMAs have covered the load latency: x^T in the second x tile, the loss inputs in
+  // one 32-row slot each; the next strip picks them up from there.
+  float *sXc = sX, *sXn = sX2;       // x tile of this strip / of the next
+  auto stash = [&](float *xt) {
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) xt[xoff[j]] = xr[j];
+    sIn[r32] = p_in0;                // (both lane halves hold, and write, the same value)
+#pragma unroll
+    for (int n = 0; n < NO; ++n) { sIn[(1 + n) * 32 + r32] = p_act[n]; sIn[(1 + NO + n) * 32 + r32] = p_olp[n]; }
+  };
+  if constexpr (STG) {
+    stash(sXc);
+    wave_lds_fence();
+  }
   PH_DECL
   for (; strip < nstrips; strip += sstride) {
     const int64_t row0 = strip << 5;
@@ -520,7 +604,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     PH(5);
 
     // ---- x^T of the strip -> sX[k][row] (the strip's rows are contiguous in obs)
-    if (XP) {
+    if constexpr (STG) {
+      // already there (stash); the loss inputs come from their slots
+    } else if (XP) {
 #pragma unroll
       for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
     } else {
@@ -533,10 +619,17 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
         if (kk >= K0) { kk -= K0; ++rr; }
       }
     }
-    const float ret = p_in0, ad = p_in0;
-    float act[NO], olp[NO];
+    float ret, act[NO], olp[NO];
+    if constexpr (STG) {
+      ret = sIn[r32];
 #pragma unroll
-    for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
+      for (int n = 0; n < NO; ++n) { act[n] = sIn[(1 + n) * 32 + r32]; olp[n] = sIn[(1 + NO + n) * 32 + r32]; }
+    } else {
+      ret = p_in0;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
+    }
+    const float ad = ret;
     fetch(strip + sstride);
     wave_lds_fence();
     PH(6);
@@ -554,7 +647,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       for (int n = 0; n < NO; ++n) pacc[n] = 0.f;
 #pragma unroll
       for (int qb = 0; qb < HB; ++qb) {
-        fwd_layer0<LDW0>(h1q[RC ? 0 : qb], sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
+        fwd_layer0<LDW0>(h1q[RC ? 0 : qb], sXc, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
         if (RC) fwd_last_acc<NO>(pacc, h1q[0], sWL + qb * NO * 64, half);
       }
       PH(7);
@@ -565,6 +658,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
           for (int qb = 0; qb < HB; ++qb) fwd_last_acc<NO>(pacc, h1q[qb], sWL + qb * NO * 64, half);
       }
+      if constexpr (STG) stash(sXn);     // the next strip's inputs have had the forward's MFMAs to arrive
       PH(8);
       fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
     }
@@ -663,7 +757,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       if (half == 0) dbL[n] += gout[n];
 #pragma unroll
     for (int qb = 0; qb < NBQ; ++qb) {    // one pass per 64-wide block of the hidden layer (HB > 1: D == 2)
-    if (RC) fwd_layer0<LDW0>(h1q[0], sX, sW0 + (qb0 + qb) * 64 * LDW0, sB + (qb0 + qb) * 64, ksteps0, half, r32);
+    if (RC) fwd_layer0<LDW0>(h1q[0], sXc, sW0 + (qb0 + qb) * 64 * LDW0, sB + (qb0 + qb) * 64, ksteps0, half, r32);
     const f32x16 (&hl)[2] = D == 3 ? h2 : h1q[RC ? 0 : qb];
     const float *sWLq = sWL + (qb0 + qb) * NO * 64;
     if constexpr (WLV) {
@@ -675,6 +769,15 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       }
       wave_lds_fence();
       rows_dwl<NO>(sH + lane * LDT, sGo, dwlv[qb]);
+    } else if constexpr (DWF) {
+      // the same through the g tile, before the layer gradient takes it (LDS operations of a wave execute in order)
+      put_tile(sG, hl, half, r32);
+      if (half == 0) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) sGo[n * LDT + r32] = gout[n];
+      }
+      wave_lds_fence();
+      rows_dwl<NO>(sG + lane * LDT, sGo, dwlv[qb]);
     }
     // ---- last layer backward (VALU): dWL, dbL partials; g = (WL^T gout) * (hl > 0)
     f32x16 g[2];
@@ -690,7 +793,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
           t[1] = fmaf(w4.y, gout[n], t[1]);
           t[2] = fmaf(w4.z, gout[n], t[2]);
           t[3] = fmaf(w4.w, gout[n], t[3]);
-          if constexpr (!WLV) {
+          if constexpr (!WLV && !DWF) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dWL[qb][n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[qb][n][kb][4 * q + i]);
           }
@@ -703,62 +806,74 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     // ---- layer 1 backward (D == 3): dW1 += g h1^T (rows through LDS), g <- (W1^T g) * (h1 > 0)
     if (D == 3) {
       put_tile(sG, g, half, r32);
-      put_tile(sH, h1, half, r32);
-      wave_lds_fence();
       // rows in the order (j, half, i) -> row 8j + 4half + i: a lane's four steps are one 16 B read
       const float *ga = sG + r32 * LDT + 4 * half, *ha = sH + r32 * LDT + 4 * half;
-      {
-        float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), x0 = ld4(ha), x1 = ld4(ha + 32 * LDT);
+      if constexpr (HT) {
+        // Eight waves, 256 registers each: the input gradient comes first (g is in registers), h1 is not held from
+        // the forward but recomputed after it (layer 0 over a fan-in <= 4 is four MFMAs), and its transpose goes
+        // through LDS one 32-feature half at a time (a wave's LDS operations execute in issue order: the second
+        // half's writes follow the first half's reads without a wait)
+        wave_lds_fence();
+        vdb1 += row_sum32(sG + lane * LDT);
+        f32x16 t[2];
+        bwd_dx1(t, g, sW1T, half, r32);
+        f32x16 h1r[2];
+        fwd_layer0<LDW0>(h1r, sXc, sW0, sB, ksteps0, half, r32);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float4 ng0 = g0, ng1 = g1, nx0 = x0, nx1 = x1;
-          if (j + 1 < 4) {
-            ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
-            nx0 = ld4(ha + 8 * (j + 1)); nx1 = ld4(ha + 32 * LDT + 8 * (j + 1));
-          }
-          issue_fence();
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            accW1[0][0] = MFMA(f4(g0, i), f4(x0, i), accW1[0][0]);
-            accW1[0][1] = MFMA(f4(g0, i), f4(x1, i), accW1[0][1]);
-            accW1[1][0] = MFMA(f4(g1, i), f4(x0, i), accW1[1][0]);
-            accW1[1][1] = MFMA(f4(g1, i), f4(x1, i), accW1[1][1]);
+          for (int r = 0; r < 16; ++r) sH[feat(r, half) * LDT + r32] = h1r[kb][r];
+          wave_lds_fence();
+          float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), x0 = ld4(ha);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float4 ng0 = g0, ng1 = g1, nx0 = x0;
+            if (j + 1 < 4) {
+              ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
+              nx0 = ld4(ha + 8 * (j + 1));
+            }
+            issue_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              accW1[0][kb] = MFMA(f4(g0, i), f4(x0, i), accW1[0][kb]);
+              accW1[1][kb] = MFMA(f4(g1, i), f4(x0, i), accW1[1][kb]);
+            }
+            g0 = ng0; g1 = ng1; x0 = nx0;
           }
-          g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) g[kb][r] = h1r[kb][r] > 0.f ? t[kb][r] : 0.f;
         }
-      }
-      vdb1 += row_sum32(sG + lane * LDT);     // db1[lane] += sum over the strip's rows of g[lane][row] (beside the MFMAs)
-      f32x16 t[2];
+      } else {
+        put_tile(sH, h1, half, r32);
+        wave_lds_fence();
+        {
+          float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), x0 = ld4(ha), x1 = ld4(ha + 32 * LDT);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+          for (int j = 0; j < 4; ++j) {
+            float4 ng0 = g0, ng1 = g1, nx0 = x0, nx1 = x1;
+            if (j + 1 < 4) {
+              ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
+              nx0 = ld4(ha + 8 * (j + 1)); nx1 = ld4(ha + 32 * LDT + 8 * (j + 1));
+            }
+            issue_fence();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t[kb][r] = 0.f;
-      {
-        // t^T[k][row] = sum_n W1[n][k] g^T[n][row]: A = W1^T[k = kb*32 + r32][n], four n per read
-        const float *wt = sW1T + r32 * LDW + 4 * half;
-        float4 a0 = ld4(wt), a1 = ld4(wt + 32 * LDW);
-#pragma unroll
-        for (int gq = 0; gq < 8; ++gq) {
-          const int nb = gq >> 2, q = gq & 3;
-          float4 n0 = a0, n1 = a1;
-          if (gq + 1 < 8) {
-            const int c = ((gq + 1) >> 2) * 32 + 8 * ((gq + 1) & 3);
-            n0 = ld4(wt + c);
-            n1 = ld4(wt + 32 * LDW + c);
+            for (int i = 0; i < 4; ++i) {
+              accW1[0][0] = MFMA(f4(g0, i), f4(x0, i), accW1[0][0]);
+              accW1[0][1] = MFMA(f4(g0, i), f4(x1, i), accW1[0][1]);
+              accW1[1][0] = MFMA(f4(g1, i), f4(x0, i), accW1[1][0]);
+              accW1[1][1] = MFMA(f4(g1, i), f4(x1, i), accW1[1][1]);
+            }
+            g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
           }
-          issue_fence();
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            t[0] = MFMA(f4(a0, i), g[nb][4 * q + i], t[0]);
-            t[1] = MFMA(f4(a1, i), g[nb][4 * q + i], t[1]);
-          }
-          a0 = n0; a1 = n1;
         }
+        vdb1 += row_sum32(sG + lane * LDT);     // db1[lane] += sum over the strip's rows of g[lane][row] (beside the MFMAs)
+        f32x16 t[2];
+        bwd_dx1(t, g, sW1T, half, r32);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) g[kb][r] = h1[kb][r] > 0.f ? t[kb][r] : 0.f;
       }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[kb][r] = h1[kb][r] > 0.f ? t[kb][r] : 0.f;
     }
 
     PH(2);
@@ -766,10 +881,10 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     put_tile(sG, g, half, r32);
     wave_lds_fence();
     PH(9);
-    if (w0v) {
-      vdb0[qb] += row_sum32_dw4(sG + lane * LDT, sX, dw0v[qb]);
-    } else {
-      const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
+    if (W0C || w0v) {
+      vdb0[qb] += row_sum32_dw4(sG + lane * LDT, sXc, dw0v[qb]);
+    } else if constexpr (!W0C) {
+      const float *ga = sG + r32 * LDT + 4 * half, *xa = sXc + r32 * LDT + 4 * half;
       float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), xv[KB0];
 #pragma unroll
       for (int kb = 0; kb < KB0; ++kb) xv[kb] = ld4(xa + kb * 32 * LDT);
@@ -797,8 +912,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       }
       vdb0[0] += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
     }
-    wave_lds_fence();     // the next block / strip overwrites sG (and sX)
+    wave_lds_fence();     // the next block / strip overwrites sG (and sXc)
     }                     // hidden blocks
+    if constexpr (STG) { float *t = sXc; sXc = sXn; sXn = t; }
     PH(3);
   }
   PH_OUT;
@@ -818,7 +934,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     for (int qb = 0; qb < NBQ; ++qb)
 #pragma unroll
       for (int n = 0; n < NO; ++n) {
-        if constexpr (WLV) {
+        if constexpr (WLV || DWF) {
           vec_wl[qb][n] = dwlv[qb][n];           // already per feature
         } else {
           put_tile(sG, dWL[qb][n], half, r32);
@@ -845,23 +961,28 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   float *mine = sT + wave * WTP;
   auto flush_tile = [&](auto &acc, int KBn, int N, int K, int off) {
     const int ld = 32 * KBn;
-    __syncthreads();     // the regions are free (previous flush / the per-wave transposes)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 2; ++nb) {      // one 32-row half of the tile per round (a half fits every wave's region)
+      __syncthreads();     // the regions are free (previous round / the per-wave transposes)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         if (kb < KBn) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mine[(nb * 32 + feat(r, half)) * ld + kb * 32 + r32] = acc(nb, kb)[r];
+          for (int r = 0; r < 16; ++r) mine[feat(r, half) * ld + kb * 32 + r32] = acc(nb, kb)[r];
         }
       }
-    __syncthreads();
-    for (int e = tid; e < N * K; e += 256) {
-      const int i = (e / K) * ld + (e % K);
-      part[off + e] = ((sT[i] + sT[WTP + i]) + sT[2 * WTP + i]) + sT[3 * WTP + i];
+      __syncthreads();
+      const int rows = N - 32 * nb < 32 ? N - 32 * nb : 32;
+      for (int e = tid; e < rows * K; e += NT) {
+        const int i = (e / K) * ld + (e % K);
+        float v = sT[i];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += sT[w * WTP + i];
+        part[off + 32 * nb * K + e] = v;
+      }
     }
   };
-  {
+  if constexpr (!W0C) {
     auto acc0 = [&](int nb, int kb) -> f32x16 & { return accW0[nb][kb < KB0 ? kb : 0]; };
     if (!w0v) flush_tile(acc0, KB0, H1, K0, a.poff[0]);     // (workgroup-uniform)
   }
@@ -873,7 +994,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // ---- per-feature vectors [wave][slot][64] and scalars [wave][16], summed in wave order
   constexpr int VS = 12;     // slots per wave: db0, db1, NO last-layer rows, 4 dW0 columns (w0v)
   static_assert(2 + NO + 4 <= VS, "vector slots");
-  float *vsum = sT, *scal = sT + 4 * VS * 64;
+  float *vsum = sT, *scal = sT + NW * VS * 64;
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
@@ -888,10 +1009,11 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) vsum[(wave * VS + 2 + NO + k) * 64 + lane] = dw0v[qb][k];
     __syncthreads();
-    for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += 4) {
+    for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += NW) {
       const int f = tid & 63, fq = (qb0 + qb) * 64 + f;
-      const float v = ((vsum[(0 * VS + sl) * 64 + f] + vsum[(1 * VS + sl) * 64 + f]) + vsum[(2 * VS + sl) * 64 + f]) +
-                      vsum[(3 * VS + sl) * 64 + f];
+      float v = vsum[(0 * VS + sl) * 64 + f];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += vsum[(w * VS + sl) * 64 + f];
       if (sl >= 2 + NO) {
         const int k = sl - 2 - NO;
         if (fq < H1 && k < K0) part[a.poff[0] + fq * K0 + k] = v;
@@ -906,7 +1028,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     }
   }
   if (tid < 2 + 2 * NO && (!RC || blockIdx.z == 0)) {
-    const float v = ((scal[0 * 16 + tid] + scal[1 * 16 + tid]) + scal[2 * 16 + tid]) + scal[3 * 16 + tid];
+    float v = scal[tid];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += scal[w * 16 + tid];
     if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
       if (tid < 2 + A) part[a.nparams + tid] = v;
     } else {                                  // dbL[n]
@@ -1193,9 +1317,9 @@ int fill_dst(const char *fn, const NetArgs &a, float *const *pg, GradDst *gd) {
   return TRL_OK;
 }
 
-inline int learn_wgs(int64_t B) {
+inline int learn_wgs(int64_t B, int nw) {
   // one workgroup per CU over both networks: 128 per network, fewer when the batch is small
-  const int64_t need = trl_cdiv(trl_cdiv(B, 32), 4);
+  const int64_t need = trl_cdiv(trl_cdiv(B, 32), nw);
   return (int)(need < 128 ? need : 128);
 }
 
@@ -1244,7 +1368,13 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   P.lo = (float)(1.0 - clip); P.hi = (float)(1.0 + clip); P.alpha = (float)alpha; P.beta = (float)beta;
   P.ws = (float *)ws;
   P.pstride = pstride_of(P.net[0].nparams, P.net[1].nparams);
-  const int nwg = learn_wgs(B);
+  // two hidden layers over a fan-in <= 4 and enough strips for 2 x 1024 waves: the eight-wave variant
+  const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
+  bool w8 = critic->depth == 3 && critic->dims[0] <= 4 && A == 1 && B >= 8 * 32 * 128;
+#ifdef TRL_TUNING
+  if (const char *e = getenv("TRL_LEARN_NW")) w8 = w8 && atoi(e) == 8;     // A/B runs of tools/ only
+#endif
+  const int nwg = learn_wgs(B, w8 ? 8 : 4);
   ReduceArgs R{};
   R.ws = (const float *)ws; R.nwg = nwg; R.pstride = P.pstride;
   R.nparams[0] = P.net[0].nparams; R.nparams[1] = P.net[1].nparams;
@@ -1271,7 +1401,7 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   }
 
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)nwg, 2), block(256);
+  const dim3 grid((unsigned)nwg, 2), block(w8 ? 512 : 256);
   const int D = critic->depth, KB0 = critic->dims[0] <= 32 ? 1 : 2, NOv = A <= 1 ? 1 : (A <= 2 ? 2 : 4);
   const bool xp = critic->dims[0] <= 12;
 #define TRL_LEARN_CASE(d, kb, no)                                                                  \
@@ -1279,8 +1409,9 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
     if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_learn<d, kb, no, kb == 1>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_learn<d, kb, no, false>), grid, block, 0, st, P);               \
   }
-  const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
-  if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
+  if (w8) {
+    hipLaunchKernelGGL((k_ac_learn<3, 1, 1, true, 1, 8>), grid, block, 0, st, P);
+  } else if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
     // (4 blocks x 2 outputs: the last layer's weight gradient is accumulated per feature from LDS tiles, WLV)
     TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
     if (hmax <= 128 && NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 2>), grid, block, 0, st, P);
