@@ -13,14 +13,16 @@ obs = torch.randn(B, 3, generator=g).to(DEV); act = torch.randn(B, 1, generator=
 ret = torch.randn(B, 1, generator=g).to(DEV); adv = torch.randn(B, 1, generator=g).to(DEV)
 old = torch.zeros(B, 1, device=DEV)
 res = {}
-for nw in ('4', '8'):
+for nw in ('4', '8', '9'):
   os.environ['TRL_LEARN_NW'] = nw
   losses = ctl._fused(obs, act, ret, old, adv, 0.2, 0.5, 1e-3)
   torch.cuda.synchronize()
   res[nw] = (losses.clone().cpu(), ctl._flat.grad.clone().cpu())
 print('losses 4:', res['4'][0].tolist())
 print('losses 8:', res['8'][0].tolist())
-d = (res['4'][1] - res['8'][1]).abs()
+print('losses 9:', res['9'][0].tolist())
+print('pairs vs 4 waves: bitwise equal grads', bool(torch.equal(res['4'][1], res['9'][1])), 'losses', bool(torch.equal(res['4'][0], res['9'][0])))
+d = (res['4'][1] - res['9'][1]).abs()
 print('grad max diff', float(d.max()), 'scale', float(res['4'][1].abs().max()))
 off = 0
 for name, p in ctl.ac_net.named_parameters():

@@ -80,6 +80,12 @@ __global__ __launch_bounds__(512) void k_two(float *out, unsigned long long *cyc
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+// which SIMD does wave w of a 512-thread workgroup run on?  (HW_ID bits 5:4)
+__global__ __launch_bounds__(512) void k_simd(unsigned *out) {
+  const unsigned id = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = id;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <int NV, int NL>
@@ -129,5 +135,16 @@ int main() {
   run_two<8>(out, cyc, h, iters);
   run_two<16>(out, cyc, h, iters);
   run_two<32>(out, cyc, h, iters);
+  {
+    unsigned *d, hsim[64];
+    CK(hipMalloc(&d, 64 * 4));
+    hipLaunchKernelGGL(k_simd, dim3(8), dim3(512), 0, 0, d);
+    CK(hipMemcpy(hsim, d, 64 * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < 8; ++b) {
+      printf("workgroup %d: SIMD of waves 0..7:", b);
+      for (int w = 0; w < 8; ++w) printf(" %u", hsim[b * 8 + w]);
+      printf("\n");
+    }
+  }
   return 0;
 }

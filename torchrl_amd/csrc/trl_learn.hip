@@ -381,6 +381,105 @@ __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, floa
   }
 }
 
+// ---- loss of one strip row and its gradient w.r.t. the network output (arithmetic of k_ppo_loss / k_a2c_loss,
+// trl_loss.hip).  `valid`: the row exists; each row's loss terms are summed once, by lane half 0.
+struct LossConst {
+  float invB, gmin;
+};
+template <int NO>
+__device__ __forceinline__ void loss_grad(const LearnArgs &P, int net, int A, bool valid, int half, const LossConst &lc,
+                                          const float (&out)[NO], float ret, float ad, const float (&act)[NO],
+                                          const float (&olp)[NO], const float (&den)[NO], const float (&var)[NO],
+                                          const float (&logsig)[NO], float (&gout)[NO], float &s_main, float &s_ent,
+                                          float (&s_dls)[NO]) {
+  const float invB = lc.invB, gmin = lc.gmin;
+  const bool count = valid && half == 0;    // each row's loss terms are summed once
+#pragma unroll
+  for (int n = 0; n < NO; ++n) gout[n] = 0.f;
+  if (net == 0) {
+    const float dv = out[0] - ret;            // mse_loss(values, returns)
+    if (count) s_main += dv * dv;
+    if (valid) gout[0] = P.alpha * ((2.0f * invB) * dv);
+  } else if (P.kind == KIND_A2C) {
+    // out = the actor's logits; nn.Softmax(dim=1) (models.py:99-103), then Categorical(probs) and
+    // the loss of a2c_controller.py:48-59 in the arithmetic of k_a2c_loss; `ad` is the detached
+    // advantage returns - V(obs) (the caller's forward-only pass)
+    float zmax = out[0];
+#pragma unroll
+    for (int n = 1; n < NO; ++n)
+      if (n < A) zmax = fmaxf(zmax, out[n]);
+    float pr[NO], esum = 0.f;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      pr[n] = n < A ? expf(out[n] - zmax) : 0.f;
+      esum += pr[n];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      pr[n] = pr[n] / esum;
+      s += pr[n];                             // Categorical: probs / probs.sum(-1, keepdim=True)
+    }
+    int ai = (int)act[0];                     // action.long()
+    ai = ai < 0 ? 0 : (ai >= A ? A - 1 : ai);
+    float ent = 0.f, gdot = 0.f, logp = 0.f, gg[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      gg[n] = 0.f;
+      if (n < A) {
+        const float pn = pr[n] / s;
+        const float cl = fminf(fmaxf(pn, F32_EPS), 1.0f - F32_EPS);   // clamp_probs
+        const float logit = logf(cl);
+        ent += fmaxf(logit, F32_LOWEST) * pn;
+        if (n == ai) logp = logit;
+        const float dlogit = (pn >= F32_EPS && pn <= 1.0f - F32_EPS) ? 1.0f / cl : 0.f;
+        float g1 = (P.beta * invB) * (logit + pn * dlogit);          // from -beta * entropy
+        if (n == ai) g1 += (-(ad * invB)) * dlogit;                   // from the actor term
+        gg[n] = g1;
+        gdot += g1 * pn;
+      }
+    }
+    float dp[NO], dsum = 0.f;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      dp[n] = n < A ? (gg[n] - gdot) / s : 0.f;                       // back through the normalisation
+      dsum += dp[n] * pr[n];
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n)
+      if (valid && n < A) gout[n] = (dp[n] - dsum) * pr[n];            // softmax backward
+    if (count) {
+      s_main += ad * logp;
+      s_ent += -ent;
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      if (n < A) {
+        const float d = act[n] - out[n];
+        const float sq = d * d;
+        const float lp = ((-sq) / den[n] - logsig[n]) - LOG_SQRT_2PI;   // Normal.log_prob
+        const float ratio = expf(lp - olp[n]);
+        const float s1 = ratio * ad;
+        const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
+        const float s2 = rc * ad;
+        // torch.minimum backward: the smaller side takes the gradient, a tie splits it
+        const float g1 = s1 < s2 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+        const float g2 = s2 < s1 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+        const bool inr = ratio >= P.lo && ratio <= P.hi;   // clamp backward mask
+        const float g_ratio = g1 * ad + (inr ? g2 * ad : 0.f);
+        const float g_lp = g_ratio * ratio;                // exp backward
+        if (count) {
+          s_main += fminf(s1, s2);
+          s_ent += ENT_CONST + logsig[n];
+          s_dls[n] += g_lp * (sq / var[n] - 1.0f);
+        }
+        if (valid) gout[n] = (g_lp / den[n]) * (2.0f * d);
+      }
+    }
+  }
+}
+
 // D = depth (2: in -> H -> out, 3: in -> H -> H -> out); KB0 = 32-blocks of the fan-in;
 // NO = padded fan-out of the last layer (actual fan-outs <= NO)
 // XP: the strip's observations are prefetched into registers (fan-in <= 12)
@@ -666,91 +765,8 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
     PH(0);
     // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
     float gout[NO];
-    const bool count = valid && half == 0;    // each row's loss terms are summed once
-#pragma unroll
-    for (int n = 0; n < NO; ++n) gout[n] = 0.f;
-    if (net == 0) {
-      const float dv = out[0] - ret;            // mse_loss(values, returns)
-      if (count) s_main += dv * dv;
-      if (valid) gout[0] = P.alpha * ((2.0f * invB) * dv);
-    } else if (P.kind == KIND_A2C) {
-      // out = the actor's logits; nn.Softmax(dim=1) (models.py:99-103), then Categorical(probs) and
-      // the loss of a2c_controller.py:48-59 in the arithmetic of k_a2c_loss; `ad` is the detached
-      // advantage returns - V(obs) (the caller's forward-only pass)
-      float zmax = out[0];
-#pragma unroll
-      for (int n = 1; n < NO; ++n)
-        if (n < A) zmax = fmaxf(zmax, out[n]);
-      float pr[NO], esum = 0.f;
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        pr[n] = n < A ? expf(out[n] - zmax) : 0.f;
-        esum += pr[n];
-      }
-      float s = 0.f;
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        pr[n] = pr[n] / esum;
-        s += pr[n];                             // Categorical: probs / probs.sum(-1, keepdim=True)
-      }
-      int ai = (int)act[0];                     // action.long()
-      ai = ai < 0 ? 0 : (ai >= A ? A - 1 : ai);
-      float ent = 0.f, gdot = 0.f, logp = 0.f, gg[NO];
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        gg[n] = 0.f;
-        if (n < A) {
-          const float pn = pr[n] / s;
-          const float cl = fminf(fmaxf(pn, F32_EPS), 1.0f - F32_EPS);   // clamp_probs
-          const float logit = logf(cl);
-          ent += fmaxf(logit, F32_LOWEST) * pn;
-          if (n == ai) logp = logit;
-          const float dlogit = (pn >= F32_EPS && pn <= 1.0f - F32_EPS) ? 1.0f / cl : 0.f;
-          float g1 = (P.beta * invB) * (logit + pn * dlogit);          // from -beta * entropy
-          if (n == ai) g1 += (-(ad * invB)) * dlogit;                   // from the actor term
-          gg[n] = g1;
-          gdot += g1 * pn;
-        }
-      }
-      float dp[NO], dsum = 0.f;
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        dp[n] = n < A ? (gg[n] - gdot) / s : 0.f;                       // back through the normalisation
-        dsum += dp[n] * pr[n];
-      }
-#pragma unroll
-      for (int n = 0; n < NO; ++n)
-        if (valid && n < A) gout[n] = (dp[n] - dsum) * pr[n];            // softmax backward
-      if (count) {
-        s_main += ad * logp;
-        s_ent += -ent;
-      }
-    } else {
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        if (n < A) {
-          const float d = act[n] - out[n];
-          const float sq = d * d;
-          const float lp = ((-sq) / den[n] - logsig[n]) - LOG_SQRT_2PI;   // Normal.log_prob
-          const float ratio = expf(lp - olp[n]);
-          const float s1 = ratio * ad;
-          const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
-          const float s2 = rc * ad;
-          // torch.minimum backward: the smaller side takes the gradient, a tie splits it
-          const float g1 = s1 < s2 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
-          const float g2 = s2 < s1 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
-          const bool inr = ratio >= P.lo && ratio <= P.hi;   // clamp backward mask
-          const float g_ratio = g1 * ad + (inr ? g2 * ad : 0.f);
-          const float g_lp = g_ratio * ratio;                // exp backward
-          if (count) {
-            s_main += fminf(s1, s2);
-            s_ent += ENT_CONST + logsig[n];
-            s_dls[n] += g_lp * (sq / var[n] - 1.0f);
-          }
-          if (valid) gout[n] = (g_lp / den[n]) * (2.0f * d);
-        }
-      }
-    }
+    loss_grad<NO>(P, net, A, valid, half, LossConst{invB, gmin}, out, ret, ad, act, olp, den, var, logsig, gout, s_main,
+                  s_ent, s_dls);
 
 #pragma unroll
     for (int n = 0; n < NO; ++n)
@@ -1043,6 +1059,354 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
 
 // ---- inference: the forward alone over B rows (PPOController.compute_return's value / mean /
 // log-prob pass, ppo_controller.py:34,48): only the outputs are written, several workgroups per CU
+// ---------------------------------------------------------------------------------------------------------------
+// Role-split variant of k_ac_learn for two hidden layers (<= 64 wide) over a fan-in <= 4 (PPO / A2C on Pendulum- or
+// CartPole-sized observations): 512 threads, and the two waves that share a SIMD (w and w + 4) share every strip.
+//
+// Why.  v_mfma_f32_32x32x2_f32 holds ITS OWN wave for its 64 cycles -- a VALU or LDS instruction behind it adds its
+// full issue time -- but another wave on the same SIMD issues VALU work at full rate meanwhile
+// (tools/mfma_valu_probe.hip: 64.1 -> 129 cycles per MFMA with 16 v_fma behind each in one wave; 64.2 cycles with the
+// same v_fma in a partner wave).  One wave per SIMD therefore pays MFMA + VALU (k_ac_learn: 20.5 k cycles per strip
+// for 12.5 k of MFMA).  Two symmetric waves per SIMD at 256 registers each do not fit this step without spills (64
+// accumulators of dW1 per wave).  So the pair splits the STEP instead of the strips:
+//   wave A (w < 4): the dependent chain -- forward, loss, last layer backward, the input gradient of layer 1, the
+//     ReLU masks -- and the transposing tile writes; it holds no weight-gradient tile;
+//   wave B (w + 4): everything that only reads A's tiles -- the 64 MFMAs of dW1, the bias-gradient row sums, the
+//     layer-0 weight gradient -- and so holds the 64 dW1 accumulators.
+// A's VALU stretches run under B's MFMAs and B's under A's.  Hand-off through one set of LDS tiles per pair and four
+// counters (LDS operations of the CU execute in issue order, so a counter written after a tile is seen after it):
+//   pub[0] strips whose g2 / h1^T tiles are written (A)    pub[2] strips whose g2 / h1^T tiles B has consumed
+//   pub[1] strips whose g1 tile is written (A)             pub[3] strips whose g1 / x^T tiles B has consumed
+// Every wait is bounded (a pair that lost its partner finishes with wrong numbers rather than hanging the GPU).
+// Strip assignment, operation order and partial-sum order are those of k_ac_learn<3, 1, NO, true> (pair p = its wave
+// p), so the two kernels give the same bits.
+__device__ __forceinline__ void pair_wait(const int *ctr, int want) {
+  for (int spin = 0; spin < (1 << 20); ++spin) {
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (v >= want) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  wave_lds_fence();
+}
+__device__ __forceinline__ void pair_post(int *ctr, int value, int lane) {
+  wave_lds_fence();      // (the tile accesses above are issued, and LDS keeps issue order)
+  if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NO>
+__global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
+  constexpr int D = 3, NT = 512, LDW0 = 5;
+  constexpr int XT = 4 * LDT + 4;                     // x^T tile: 4 rows (+ a dummy slot for idle prefetch lanes)
+  constexpr int OFF_B = 0;                            // b0, b1, bL
+  constexpr int OFF_WL = OFF_B + 64 + 64 + 4;
+  constexpr int OFF_W0 = OFF_WL + NO * 64;
+  constexpr int OFF_W1 = OFF_W0 + 64 * LDW0;
+  constexpr int OFF_W1T = OFF_W1 + 64 * LDW;
+  constexpr int OFF_T = OFF_W1T + 64 * LDW;
+  constexpr int PT = 2 * XT + 3 * 64 * LDT + 8;       // per pair: two x tiles, g2, h1^T, g1 tiles, the counters
+  __shared__ __align__(16) float smem[OFF_T + 4 * PT];
+  float *const sB = smem + OFF_B, *const sWL = smem + OFF_WL, *const sW0 = smem + OFF_W0, *const sW1 = smem + OFF_W1,
+               *const sW1T = smem + OFF_W1T, *const sT = smem + OFF_T;
+  static_assert(PT >= 32 * 64 && 4 * PT >= 4 * 12 * 64 + 64, "the end-of-kernel reduction re-uses the pair regions");
+
+  const int net = blockIdx.y;
+  const NetArgs &a = P.net[net];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5,
+            r32 = lane & 31;
+  const int pair = wave & 3;
+  const bool roleA = wave < 4;
+  const int K0 = a.dims[0], H1 = a.dims[1], HL = a.dims[2], NOr = a.dims[3];
+  const int64_t B = P.B;
+  const int A = P.A;
+
+  stage_weights<D, LDW0, NO, true, 1, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
+  float *sXp = sT + pair * PT;          // [2][XT]     x^T of the strip, alternating
+  float *sG2 = sXp + 2 * XT;            // [64][LDT]   gradient w.r.t. layer 1's pre-activation
+  float *sH1 = sG2 + 64 * LDT;          // [64][LDT]   h1^T
+  float *sG1 = sH1 + 64 * LDT;          // [64][LDT]   gradient w.r.t. layer 0's pre-activation
+  int *pub = (int *)(sG1 + 64 * LDT);   // [4]         hand-off counters
+  if (roleA) {
+    for (int e = lane; e < 2 * XT; e += 64) sXp[e] = 0.f;   // rows >= K0 stay zero for good
+    if (lane < 8) pub[lane] = 0;
+  }
+  __syncthreads();
+
+  const int64_t nstrips = (B + 31) >> 5;
+  const int64_t sstride = (int64_t)gridDim.x * 4;
+  int64_t strip = (int64_t)blockIdx.x * 4 + pair;
+
+  // What a role hands to the end-of-kernel sums.  The big per-role state (A: the last layer's per-lane gradient
+  // partials; B: the dW1 accumulators) is declared inside its role's branch, so that it takes no registers in the
+  // other role's loop; each branch parks it in LDS before the common code.  Both branches execute the same number
+  // of workgroup barriers.
+  float vdb0 = 0.f, vdb1 = 0.f, dw0v[4] = {0.f, 0.f, 0.f, 0.f};      // B
+  float vec_wl[NO], sc[2 + 2 * NO];                                  // A
+#pragma unroll
+  for (int n = 0; n < NO; ++n) vec_wl[n] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2 + 2 * NO; ++j) sc[j] = 0.f;
+  float *mine = sT + pair * PT;         // after the loops: [64][64] dW1 tile of the pair (B), then A's transposes
+  static_assert(PT >= 64 * 64 + 64 * LDT, "the pair region holds B's dW1 tile and A's transpose tile");
+
+  if (roleA) {
+    // =================================================================================== wave A: the chain
+    f32x16 dWL[NO][2];
+    float dbL[NO], s_main = 0.f, s_ent = 0.f, s_dls[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      dbL[n] = 0.f; s_dls[n] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dWL[n][kb][r] = 0.f;
+    }
+    float den[NO], var[NO], logsig[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      den[n] = var[n] = 1.f; logsig[n] = 0.f;
+      if (net == 1 && P.kind == KIND_PPO && n < A) {
+        const float sigma = expf(P.log_std[n]);   // self.log_std.exp()
+        var[n] = uni(sigma * sigma);              // scale ** 2
+        logsig[n] = uni(logf(sigma));             // scale.log()
+        den[n] = uni(2.0f * (sigma * sigma));
+      }
+    }
+    const LossConst lc{uni(1.0f / (float)B), uni(-(1.0f / (float)(B * A)))};
+    const int q64 = 64 / K0, m64 = 64 % K0;
+    const int ksteps0 = (K0 + 1) >> 1;
+    constexpr int XPF = 2;               // 32 rows x fan-in <= 4: at most 128 elements
+    const int nelem = 32 * K0;
+    int xoff[XPF];
+    {
+      int rr = lane / K0, kk = lane % K0;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) {
+        xoff[j] = lane + 64 * j < nelem ? kk * LDT + rr : XT - 4;
+        rr += q64; kk += m64;
+        if (kk >= K0) { kk -= K0; ++rr; }
+      }
+    }
+    const float *in0 = net == 0 ? P.returns : P.adv;
+    const float *in_act[NO], *in_olp[NO];
+    const bool ppo_actor = net == 1 && P.kind == KIND_PPO;
+    const int astr = ppo_actor ? A : 1;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      in_act[n] = net == 0 ? in0 : (ppo_actor ? P.action + (n < A ? n : 0) : P.action);
+      in_olp[n] = ppo_actor ? P.old_logp + (n < A ? n : 0) : in0;
+    }
+    float xr[XPF], p_in0 = 0.f, p_act[NO], p_olp[NO];
+    auto fetch = [&](int64_t st) {      // (st is wave-uniform: scalar bases, 32-bit lane offsets)
+      st = st < nstrips ? st : nstrips - 1;
+      const int64_t row0 = st << 5;
+      const int64_t left = B - row0;
+      const int rows = (int)(left < 32 ? left : 32);
+      const int rl = r32 < rows ? r32 : rows - 1;
+      const float *base = P.obs + row0 * K0;
+      const int last = rows * K0 - 1;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) {
+        const int e = lane + 64 * j;
+        xr[j] = base[e < last ? e : last];
+      }
+      p_in0 = (in0 + row0)[rl];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        p_act[n] = (in_act[n] + row0 * astr)[rl * astr];
+        p_olp[n] = (in_olp[n] + row0 * astr)[rl * astr];
+      }
+    };
+    fetch(strip);
+    for (int it = 0; strip < nstrips; strip += sstride, ++it) {
+      const int64_t row0 = strip << 5;
+      const bool valid = row0 + r32 < B;
+      // x^T of the strip (B read this buffer for strip it - 2; the g1 wait of strip it - 1 has covered that)
+      float *sX = sXp + (it & 1) * XT;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
+      const float ret = p_in0, ad = p_in0;
+      float act[NO], olp[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
+      fetch(strip + sstride);
+      wave_lds_fence();
+
+      f32x16 h1[2], h2[2];
+      float out[NO];
+      fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+      fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+      fwd_last<NO>(out, h2, sWL, sB + 128, half);
+
+      float gout[NO];
+      loss_grad<NO>(P, net, A, valid, half, lc, out, ret, ad, act, olp, den, var, logsig, gout, s_main, s_ent, s_dls);
+#pragma unroll
+      for (int n = 0; n < NO; ++n)
+        if (half == 0) dbL[n] += gout[n];
+
+      // last layer backward (VALU): dWL partials per lane; g = (WL^T gout) * (h2 > 0)
+      f32x16 g[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int n = 0; n < NO; ++n) {
+            const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
+            t[0] = fmaf(w4.x, gout[n], t[0]);
+            t[1] = fmaf(w4.y, gout[n], t[1]);
+            t[2] = fmaf(w4.z, gout[n], t[2]);
+            t[3] = fmaf(w4.w, gout[n], t[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dWL[n][kb][4 * q + i] = fmaf(gout[n], h2[kb][4 * q + i], dWL[n][kb][4 * q + i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = h2[kb][4 * q + i] > 0.f ? t[i] : 0.f;
+        }
+
+      // publish g2 and h1^T (B has consumed the previous strip's)
+      pair_wait(pub + 2, it);
+      put_tile(sG2, g, half, r32);
+      put_tile(sH1, h1, half, r32);
+      pair_post(pub + 0, it + 1, lane);
+
+      // layer 1 backward, input side, and its mask
+      f32x16 t[2];
+      bwd_dx1(t, g, sW1T, half, r32);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[kb][r] = h1[kb][r] > 0.f ? t[kb][r] : 0.f;
+
+      pair_wait(pub + 3, it);
+      put_tile(sG1, g, half, r32);
+      pair_post(pub + 1, it + 1, lane);
+    }
+    __syncthreads();      // (1) every pair is through its strips: the pair regions are free
+    // per-lane partial vectors dWL[n] -> per-feature sums over the wave's 32 rows, through a tile behind B's
+    float *tr = mine + 64 * 64;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      put_tile(tr, dWL[n], half, r32);
+      wave_lds_fence();
+      float sum = 0.f;
+      for (int r = 0; r < 32; ++r) sum += tr[lane * LDT + r];
+      vec_wl[n] = sum;
+      wave_lds_fence();
+    }
+    sc[0] = trl_wave_sum(s_main);
+    sc[1] = trl_wave_sum(s_ent);
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      sc[2 + n] = trl_wave_sum(s_dls[n]);
+      sc[2 + NO + n] = trl_wave_sum(dbL[n]);
+    }
+  } else {
+    // =================================================================================== wave B: the tiles' readers
+    f32x16 accW1[2][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW1[nb][kb][r] = 0.f;
+    const float *ga = sG2 + r32 * LDT + 4 * half, *ha = sH1 + r32 * LDT + 4 * half;
+    for (int it = 0; strip < nstrips; strip += sstride, ++it) {
+      // dW1 += g2 h1^T: rows in the order (j, half, i) -> row 8j + 4half + i, a lane's four steps are one 16 B read
+      pair_wait(pub + 0, it + 1);
+      {
+        float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), x0 = ld4(ha), x1 = ld4(ha + 32 * LDT);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 ng0 = g0, ng1 = g1, nx0 = x0, nx1 = x1;
+          if (j + 1 < 4) {
+            ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
+            nx0 = ld4(ha + 8 * (j + 1)); nx1 = ld4(ha + 32 * LDT + 8 * (j + 1));
+          }
+          issue_fence();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            accW1[0][0] = MFMA(f4(g0, i), f4(x0, i), accW1[0][0]);
+            accW1[0][1] = MFMA(f4(g0, i), f4(x1, i), accW1[0][1]);
+            accW1[1][0] = MFMA(f4(g1, i), f4(x0, i), accW1[1][0]);
+            accW1[1][1] = MFMA(f4(g1, i), f4(x1, i), accW1[1][1]);
+          }
+          g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
+        }
+      }
+      vdb1 += row_sum32(sG2 + lane * LDT);
+      pair_post(pub + 2, it + 1, lane);
+
+      // layer 0: db0 and dW0 (VALU, fan-in <= 4)
+      pair_wait(pub + 1, it + 1);
+      vdb0 += row_sum32_dw4(sG1 + lane * LDT, sXp + (it & 1) * XT, dw0v);
+      pair_post(pub + 3, it + 1, lane);
+    }
+    __syncthreads();      // (1)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(nb * 32 + feat(r, half)) * 64 + kb * 32 + r32] = accW1[nb][kb][r];
+  }
+
+  // =========================================================================== partials out
+  __syncthreads();        // (2)
+  float *part = P.ws + ((int64_t)net * gridDim.x + blockIdx.x) * P.pstride;
+  {
+    // dW1: the four pairs' tiles, added in pair order
+    const int N = a.dims[2], K = H1, off = a.poff[1];
+    for (int e = tid; e < N * K; e += NT) {
+      const int i = (e / K) * 64 + (e % K);
+      part[off + e] = ((sT[i] + sT[PT + i]) + sT[2 * PT + i]) + sT[3 * PT + i];
+    }
+  }
+  __syncthreads();
+  // per-feature vectors [pair][slot][64] and scalars [pair][16], summed in pair order
+  constexpr int VS = 12;     // slots: db0, db1, NO last-layer rows, 4 dW0 columns
+  float *vsum = sT, *scal = sT + 4 * VS * 64;
+  if (roleA) {
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 2 + 2 * NO; ++j) scal[pair * 16 + j] = sc[j];
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) vsum[(pair * VS + 2 + n) * 64 + lane] = vec_wl[n];
+  } else {
+    vsum[(pair * VS + 0) * 64 + lane] = vdb0;
+    vsum[(pair * VS + 1) * 64 + lane] = vdb1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vsum[(pair * VS + 2 + NO + k) * 64 + lane] = dw0v[k];
+  }
+  __syncthreads();
+  for (int sl = tid >> 6; sl < 2 + NO + 4; sl += 8) {
+    const int f = tid & 63;
+    const float v = ((vsum[(0 * VS + sl) * 64 + f] + vsum[(1 * VS + sl) * 64 + f]) + vsum[(2 * VS + sl) * 64 + f]) +
+                    vsum[(3 * VS + sl) * 64 + f];
+    if (sl >= 2 + NO) {
+      const int k = sl - 2 - NO;
+      if (f < H1 && k < K0) part[a.poff[0] + f * K0 + k] = v;
+    } else if (sl == 0) {
+      if (f < H1) part[a.poff[0] + H1 * K0 + f] = v;
+    } else if (sl == 1) {
+      if (f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
+    } else {
+      const int n = sl - 2;
+      if (f < HL && n < NOr) part[a.poff[2] + n * HL + f] = v;
+    }
+  }
+  if (tid < 2 + 2 * NO) {
+    const float v = ((scal[0 * 16 + tid] + scal[1 * 16 + tid]) + scal[2 * 16 + tid]) + scal[3 * 16 + tid];
+    if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
+      if (tid < 2 + A) part[a.nparams + tid] = v;
+    } else {                                  // dbL[n]
+      const int n = tid - 2 - NO;
+      if (n < NOr) part[a.poff[2] + NOr * HL + n] = v;
+    }
+  }
+}
+
 struct InferArgs {
   NetArgs net[2];
   int32_t which[2];     // blockIdx.y -> network index
@@ -1370,11 +1734,16 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   P.pstride = pstride_of(P.net[0].nparams, P.net[1].nparams);
   // two hidden layers over a fan-in <= 4 and enough strips for 2 x 1024 waves: the eight-wave variant
   const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
-  bool w8 = critic->depth == 3 && critic->dims[0] <= 4 && A == 1 && B >= 8 * 32 * 128;
+  bool w8 = critic->depth == 3 && critic->dims[0] <= 4 && A <= 2 && B >= 8 * 32 * 128;
+  bool pairk = true;       // role-split pairs (k_ac_learn_pair); false: the symmetric eight-wave variant (A == 1)
 #ifdef TRL_TUNING
-  if (const char *e = getenv("TRL_LEARN_NW")) w8 = w8 && atoi(e) == 8;     // A/B runs of tools/ only
+  if (const char *e = getenv("TRL_LEARN_NW")) {     // A/B runs of tools/ only: 4, 8 (symmetric), 9 (pairs)
+    w8 = w8 && atoi(e) >= 8;
+    pairk = atoi(e) != 8;
+  }
 #endif
-  const int nwg = learn_wgs(B, w8 ? 8 : 4);
+  if (!pairk) w8 = w8 && A == 1;
+  const int nwg = learn_wgs(B, w8 && !pairk ? 8 : 4);
   ReduceArgs R{};
   R.ws = (const float *)ws; R.nwg = nwg; R.pstride = P.pstride;
   R.nparams[0] = P.net[0].nparams; R.nparams[1] = P.net[1].nparams;
@@ -1410,7 +1779,9 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
     else hipLaunchKernelGGL((k_ac_learn<d, kb, no, false>), grid, block, 0, st, P);               \
   }
   if (w8) {
-    hipLaunchKernelGGL((k_ac_learn<3, 1, 1, true, 1, 8>), grid, block, 0, st, P);
+    if (pairk && NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair<1>), grid, block, 0, st, P);
+    else if (pairk) hipLaunchKernelGGL((k_ac_learn_pair<2>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_ac_learn<3, 1, 1, true, 1, 8>), grid, block, 0, st, P);
   } else if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
     // (4 blocks x 2 outputs: the last layer's weight gradient is accumulated per feature from LDS tiles, WLV)
     TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
