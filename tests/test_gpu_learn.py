@@ -20,7 +20,7 @@ DEV = 'cuda:0'
 CASES = [(3, 1, (64, 64), 65536), (3, 1, (64, 64), 4097), (4, 2, (64, 64), 9000), (17, 2, (48, 33), 5000),
          (40, 1, (64, 64), 3000), (64, 2, (64, 64), 2048), (3, 1, (64,), 8192), (5, 4, (64,), 7001),
          (33, 3, (20,), 300), (3, 1, (64, 64), 256),
-         # two hidden layers over <= 4 observations at >= 32768 rows: the eight-wave variant (two waves per SIMD)
+         # two hidden layers over <= 4 observations at >= 32768 rows: the role-split kernel (k_ac_learn_pair)
          (3, 1, (64, 64), 40001), (4, 2, (64, 64), 33000), (2, 2, (48, 33), 50000), (1, 1, (64, 20), 32768),
          # one hidden layer wider than 64 over <= 4 observations (ppo_controller.py:14 builds 256): hidden blocks
          (3, 1, (256,), 65536), (3, 1, (256,), 4097), (4, 1, (200,), 3000), (4, 2, (128,), 5000), (2, 2, (100,), 900),
@@ -153,7 +153,7 @@ def test_compute_return_fused_equals_general_path(monkeypatch):
     torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('obs_size,A,hidden,B', [(4, 2, 64, 9001), (4, 2, (64, 64), 4096), (8, 4, 48, 5000),
+@pytest.mark.parametrize('obs_size,A,hidden,B', [(4, 2, 64, 9001), (4, 2, (64, 64), 4096), (4, 2, (64, 64), 40000), (8, 4, 48, 5000),
                                                  (40, 3, 64, 700), (3, 1, (33, 20), 2048), (4, 2, 128, 9001),
                                                  (4, 2, 100, 700), (4, 2, 256, 9001), (4, 2, 180, 1500)])
 def test_fused_a2c_learn_matches_oracle(obs_size, A, hidden, B):

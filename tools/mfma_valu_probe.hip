@@ -80,6 +80,164 @@ __global__ __launch_bounds__(512) void k_two(float *out, unsigned long long *cyc
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+// 512 threads: waves 0-3 stream MFMAs (or idle, ALONE); the partner runs 256 v_fma per round as NC independent
+// dependency chains: what a dependent VALU instruction costs beside the partner's MFMA stream
+template <int NC, bool ALONE>
+__global__ __launch_bounds__(512) void k_chain(float *out, unsigned long long *cyc, int iters, float seed) {
+  const int wave = threadIdx.x >> 6;
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float v[16];
+  for (int j = 0; j < 16; ++j) v[j] = seed + j;
+  float a = seed + threadIdx.x, b = seed * 2.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < 4) {
+    if (!ALONE)
+      for (int it = 0; it < 24 * iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = MFMA(a, b, acc[j]);
+      }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 256; ++k) v[k % NC] = __builtin_fmaf(v[k % NC], a, b);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+  for (int j = 0; j < 16; ++j) s += v[j];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+// 512 threads: waves 0-3 stream MFMAs; the partner runs NP (compare, select) pairs per slot -- v_cmp writes VCC, a
+// scalar register pair -- or, MODE 1, the same selection by integer arithmetic (no scalar register involved)
+template <int NP, int MODE>
+__global__ __launch_bounds__(512) void k_cmp(float *out, unsigned long long *cyc, int iters, float seed) {
+  const int wave = threadIdx.x >> 6;
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float v[16], h[16];
+  for (int j = 0; j < 16; ++j) { v[j] = seed + j; h[j] = seed * (j - 8) + threadIdx.x * 1e-3f; }
+  float a = seed + threadIdx.x, b = seed * 2.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < 4) {
+    if (MODE < 2)
+      for (int it = 0; it < 8 * iters; ++it) {      // (long enough that the partner always runs beside the stream)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = MFMA(a, b, acc[j]);
+      }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int q = (j * NP + k) & 15;
+          if ((MODE & 1) == 0) {
+            v[q] = h[q] > 0.f ? v[q] + a : 0.f;
+          } else {
+            const int m = (0 - __float_as_int(h[q])) >> 31;
+            v[q] = __int_as_float(__float_as_int(v[q] + a) & m);
+          }
+          asm volatile("" : "+v"(h[q]));
+        }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+  for (int j = 0; j < 16; ++j) s += v[j] + h[j];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+// 512 threads: waves 0-3 (or 4-7 when SWAP) stream MFMAs, the partner waves run NW ds_write_b32 + NR ds_read_b128 per
+// slot (the reads are consumed): does LDS traffic of the partner proceed beside the MFMA stream?
+template <int NWR, int NRD, bool SWAP>
+__global__ __launch_bounds__(512) void k_lds(float *out, unsigned long long *cyc, int iters, float seed) {
+  __shared__ __align__(16) float lds[8 * 2304];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float *mine = lds + wave * 2304;
+  for (int i = lane; i < 2304; i += 64) mine[i] = seed * i;
+  __syncthreads();
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float a = seed + threadIdx.x, b = seed * 2.f, v = seed;
+  const bool mf = SWAP ? wave >= 4 : wave < 4;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (mf) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = MFMA(a, b, acc[j]);
+    }
+  } else {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < NWR; ++k) mine[k * 36 + (lane & 31) + 144 * (lane >> 5)] = v + k;
+#pragma unroll
+      for (int k = 0; k < NRD; ++k) {
+        const v4f t = *(const v4f *)(mine + (lane & 31) * 36 + 4 * (lane >> 5) + 8 * (k & 3));
+        v += t.x;
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = v;
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+// 512 threads, both waves of a SIMD issue MFMAs.  Waves 0-3: phases of MA dependent MFMAs (two accumulators) and
+// VA v_fma; waves 4-7: phases of MB independent MFMAs (four accumulators) and VB v_fma.  Work is fixed; the wall
+// time of the pair tells whether one wave's MFMAs fill the other's VALU phases.
+template <int MA, int VA, int MB, int VB, int PRIO>
+__global__ __launch_bounds__(512) void k_mix(float *out, unsigned long long *cyc, int iters, float seed) {
+  const int wave = threadIdx.x >> 6;
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float v[16];
+  for (int j = 0; j < 16; ++j) v[j] = seed + j;
+  float a = seed + threadIdx.x, b = seed * 2.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < 4) {
+    for (int it = 0; it < iters; ++it) {
+      if (PRIO) __builtin_amdgcn_s_setprio(PRIO);      // matrix phase: this wave's (rare) issues go first
+#pragma unroll
+      for (int j = 0; j < MA; ++j) acc[j & 1] = MFMA(a, b, acc[j & 1]);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);         // vector phase: yield to the partner's MFMA issues
+#pragma unroll
+      for (int k = 0; k < VA; ++k) v[k & 15] = __builtin_fmaf(v[k & 15], a, b);
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+      if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+#pragma unroll
+      for (int j = 0; j < MB; ++j) acc[j & 3] = MFMA(a, b, acc[j & 3]);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int k = 0; k < VB; ++k) v[k & 15] = __builtin_fmaf(v[k & 15], a, b);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+  for (int j = 0; j < 16; ++j) s += v[j];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
 // which SIMD does wave w of a 512-thread workgroup run on?  (HW_ID bits 5:4)
 __global__ __launch_bounds__(512) void k_simd(unsigned *out) {
   const unsigned id = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
@@ -114,6 +272,63 @@ void run_two(float *out, unsigned long long *cyc, unsigned long long *h, int ite
          sm / 1024 / iters / 4, NV, sv / 1024 / iters / 4, sv / 1024 / iters / 4 / NV);
 }
 
+template <int NC, bool ALONE>
+void run_chain(float *out, unsigned long long *cyc, unsigned long long *h, int iters) {
+  hipLaunchKernelGGL((k_chain<NC, ALONE>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  hipLaunchKernelGGL((k_chain<NC, ALONE>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h, cyc, 2048 * 8, hipMemcpyDeviceToHost));
+  double sv = 0;
+  for (int b = 0; b < 256; ++b)
+    for (int w = 4; w < 8; ++w) sv += (double)h[b * 8 + w];
+  printf("chain: %s: v_fma in %2d independent chains: %6.2f cycles per instruction\n", ALONE ? "alone                " : "beside an MFMA stream",
+         NC, sv / 1024 / iters / 256);
+}
+
+template <int NP, int MODE>
+void run_cmp(float *out, unsigned long long *cyc, unsigned long long *h, int iters) {
+  hipLaunchKernelGGL((k_cmp<NP, MODE>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  hipLaunchKernelGGL((k_cmp<NP, MODE>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h, cyc, 2048 * 8, hipMemcpyDeviceToHost));
+  double sm = 0, sv = 0;
+  for (int b = 0; b < 256; ++b)
+    for (int w = 0; w < 8; ++w) (w < 4 ? sm : sv) += (double)h[b * 8 + w];
+  printf("cmp: %s; partner with %2d %s: %7.1f cycles per group of %d\n", MODE < 2 ? "beside an MFMA stream" : "alone                ",
+         NP, (MODE & 1) ? "(add, sub, ashr, and)" : "(add, v_cmp, v_cndmask)", sv / 1024 / iters / 4, NP);
+}
+
+template <int NWR, int NRD, bool SWAP>
+void run_lds(float *out, unsigned long long *cyc, unsigned long long *h, int iters) {
+  hipLaunchKernelGGL((k_lds<NWR, NRD, SWAP>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  hipLaunchKernelGGL((k_lds<NWR, NRD, SWAP>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h, cyc, 2048 * 8, hipMemcpyDeviceToHost));
+  double sm = 0, sv = 0;
+  for (int b = 0; b < 256; ++b)
+    for (int w = 0; w < 8; ++w) ((SWAP ? w >= 4 : w < 4) ? sm : sv) += (double)h[b * 8 + w];
+  printf("lds (MFMA stream in waves %s): MFMA wave %7.1f cycles per MFMA; partner with %2d ds_write_b32 + %2d ds_read_b128 per slot: %7.1f cycles per slot\n",
+         SWAP ? "4-7" : "0-3", sm / 1024 / iters / 4, NWR, NRD, sv / 1024 / iters / 4);
+}
+
+template <int MA, int VA, int MB, int VB, int PRIO>
+void run_mix(float *out, unsigned long long *cyc, unsigned long long *h, int iters) {
+  hipLaunchKernelGGL((k_mix<MA, VA, MB, VB, PRIO>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  hipLaunchKernelGGL((k_mix<MA, VA, MB, VB, PRIO>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h, cyc, 2048 * 8, hipMemcpyDeviceToHost));
+  double sa = 0, sb = 0;
+  for (int b = 0; b < 256; ++b)
+    for (int w = 0; w < 8; ++w) (w < 4 ? sa : sb) += (double)h[b * 8 + w];
+  sa /= 1024.0 * iters; sb /= 1024.0 * iters;
+  printf("mix (setprio %d in matrix phases): A %3d MFMA + %3d v_fma per round: %8.0f cycles; B %3d MFMA + %3d v_fma: %8.0f cycles; MFMA pipe need %d, A alone %d, B alone %d\n",
+         PRIO, MA, VA, sa, MB, VB, sb, 64 * (MA + MB), 64 * MA + 4 * VA, 64 * MB + 4 * VB);
+}
+
 int main() {
   float *out;
   unsigned long long *cyc, *h = (unsigned long long *)malloc(2048 * 8);
@@ -135,6 +350,36 @@ int main() {
   run_two<8>(out, cyc, h, iters);
   run_two<16>(out, cyc, h, iters);
   run_two<32>(out, cyc, h, iters);
+  run_chain<1, true>(out, cyc, h, 200);
+  run_chain<1, false>(out, cyc, h, 200);
+  run_chain<2, true>(out, cyc, h, 200);
+  run_chain<2, false>(out, cyc, h, 200);
+  run_chain<4, false>(out, cyc, h, 200);
+  run_chain<8, false>(out, cyc, h, 200);
+  run_chain<16, true>(out, cyc, h, 200);
+  run_chain<16, false>(out, cyc, h, 200);
+  run_cmp<16, 0>(out, cyc, h, 1000);
+  run_cmp<16, 2>(out, cyc, h, 1000);
+  run_cmp<16, 1>(out, cyc, h, 1000);
+  run_cmp<16, 3>(out, cyc, h, 1000);
+  run_lds<8, 0, false>(out, cyc, h, 2000);
+  run_lds<8, 0, true>(out, cyc, h, 2000);
+  run_lds<0, 4, false>(out, cyc, h, 2000);
+  run_lds<0, 4, true>(out, cyc, h, 2000);
+  run_lds<8, 2, false>(out, cyc, h, 2000);
+  run_lds<8, 2, true>(out, cyc, h, 2000);
+  run_mix<64, 0, 64, 0, 0>(out, cyc, h, 200);
+  run_mix<64, 0, 64, 0, 2>(out, cyc, h, 200);
+  run_mix<64, 1000, 64, 0, 0>(out, cyc, h, 200);
+  run_mix<64, 1000, 64, 0, 2>(out, cyc, h, 200);
+  run_mix<64, 1000, 64, 1000, 0>(out, cyc, h, 200);
+  run_mix<64, 1000, 64, 1000, 2>(out, cyc, h, 200);
+  run_mix<68, 600, 128, 400, 0>(out, cyc, h, 200);
+  run_mix<68, 600, 128, 400, 2>(out, cyc, h, 200);
+  run_mix<132, 700, 64, 300, 0>(out, cyc, h, 200);
+  run_mix<132, 700, 64, 300, 2>(out, cyc, h, 200);
+  run_mix<16, 250, 16, 250, 0>(out, cyc, h, 400);
+  run_mix<16, 250, 16, 250, 2>(out, cyc, h, 400);
   {
     unsigned *d, hsim[64];
     CK(hipMalloc(&d, 64 * 4));

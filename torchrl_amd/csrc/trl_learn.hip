@@ -71,6 +71,7 @@ struct LearnArgs {
   float lo, hi, alpha, beta;
   float *ws;            // [2][gridDim.x][pstride]
   int32_t pstride;
+  int32_t tune_prio;    // (tuning build) wave priorities of k_ac_learn_pair: A in bits 1:0, B in bits 3:2
 };
 constexpr int KIND_PPO = 0, KIND_A2C = 1;
 constexpr float F32_EPS = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps
@@ -106,11 +107,21 @@ constexpr float F32_LOWEST = -3.4028234663852886e+38f;
       for (int k = 0; k < 12; ++k) sp[k] = ph_acc[k];                                                    \
     }                                                                                                   \
   } while (0)
+// absolute shader-clock stamps of four consecutive strips of every pair of workgroup 0 (tools/learn_pair_trace.py)
+#define TRACE(slot)                                                                                            \
+  do {                                                                                                         \
+    if (blockIdx.x == 0 && it >= 8 && it < 12 && lane == 0) {                                                  \
+      unsigned long long *tp = (unsigned long long *)(P.ws + 2ll * 128 * P.pstride) + 2 * 128 * 8 * 8 * 3 +   \
+                               ((((int64_t)net * 4 + pair) * 4 + (it - 8)) * 2 + (roleA ? 0 : 1)) * 8;        \
+      tp[slot] = __builtin_amdgcn_s_memtime();                                                                 \
+    }                                                                                                          \
+  } while (0)
 #else
 #define STAMP(i)
 #define PH_DECL
 #define PH(k)
 #define PH_OUT
+#define TRACE(slot)
 #endif
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -487,30 +498,18 @@ __device__ __forceinline__ void loss_grad(const LearnArgs &P, int net, int A, bo
 // fan-in of at most 4, where a hidden layer of up to 256 units (the reference's own ActorCriticNet / A2CNet
 // width, ppo_controller.py:14) is walked block by block inside the wave: that shape has no square product at
 // all, only layer 0, the last layer's dot product and their transposes, each per block.
-// NW = wavefronts per workgroup.  4: one wave per SIMD with the whole register file.  8 (two hidden layers over a
-// fan-in of at most 4): two waves per SIMD at 256 registers each, so that one wave's VALU / LDS stretches (ReLU
-// masks, last layer, loss, the transposes) run under the other's MFMAs -- a single wave cannot overlap them with its
-// own dependent MFMA chain.  To fit eight waves' tiles in LDS the x tile shrinks to the 4 rows a fan-in <= 4 uses,
-// and the h1^T tile of the layer-1 weight gradient to one 32-feature half, written and consumed twice.
-template <int D, int KB0, int NO, bool XP, int HB = 1, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
+template <int D, int KB0, int NO, bool XP, int HB = 1>
+__global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
-  static_assert(NW == 4 || (NW == 8 && D == 3 && KB0 == 1 && XP && HB == 1), "eight waves: two hidden layers, fan-in <= 4");
-  constexpr int NT = 64 * NW;
-  constexpr bool W0C = NW == 8;                      // layer-0 weight gradient on the VALU, known at compile time
-  constexpr bool HT = NW == 8;                       // half h1^T tile
-  constexpr bool STG = NW == 8;                      // inputs of the next strip wait in LDS, not in registers
-  constexpr int LDW0 = W0C ? 5 : 32 * KB0 + 1;
-  constexpr int XROWS = W0C ? 4 : 32 * KB0;
-  constexpr int XT = XROWS * LDT + 4;                // floats of the x tile (+ a dummy slot for idle prefetch lanes)
+  constexpr int NW = 4, NT = 64 * NW;                // one wave per SIMD, with the whole register file
+  constexpr int LDW0 = 32 * KB0 + 1;
+  constexpr int XT = 32 * KB0 * LDT + 4;             // floats of the x tile (+ a dummy slot for idle prefetch lanes)
   // WLV: 4 hidden blocks x 2 outputs.  The last layer's weight gradient is accumulated per feature from LDS tiles
   // (rows_dwl) instead of per lane in 256 registers; the activation tile and the output-gradient rows it reads
   // take the place D == 3 uses for h1^T (+ 4 rows)
   constexpr bool WLV = HB * NO > 4;
-  constexpr bool DWF = NW == 8;                      // last-layer weight gradient per feature, through the g tile
-  constexpr int GOR = WLV ? 4 : (DWF ? NO : 0);      // rows of the output-gradient tile
-  constexpr int SIN = STG ? XT + (1 + 2 * NO) * 32 : 0;   // second x tile + one 32-row slot per loss input
-  constexpr int WT = XT + 64 * LDT + (D == 3 ? (HT ? 32 : 64) * LDT : 0) + (WLV ? 64 * LDT : 0) + GOR * LDT + SIN;   // per-wave scratch
+  constexpr int GOR = WLV ? 4 : 0;                   // rows of the output-gradient tile
+  constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0) + (WLV ? 64 * LDT : 0) + GOR * LDT;   // per-wave scratch
   constexpr int WTP = (WT + 3) & ~3;
   // One LDS array, carved by hand with the weights first: everything every strip reads (biases, last layer, W0, W1,
   // W1^T) then sits below 64 KB, within reach of a ds instruction's 16-bit offset from a lane's base register.
@@ -544,18 +543,13 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
   float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
   float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
   float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T; (WLV) the block's activations
-  float *sGo = sX + WT - SIN - GOR * LDT;   // [GOR][LDT]  (WLV, DWF) gradient w.r.t. the outputs, one row per output
-  float *sX2 = sX + WT - SIN;       // (STG) the other x tile, then the loss inputs [1 + 2 NO][32]
-  float *sIn = sX2 + XT;
+  float *sGo = sX + WT - GOR * LDT; // [GOR][LDT]  (WLV) gradient w.r.t. the outputs, one row per output
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;   // rows >= K0 stay zero for good
-  if (STG)
-    for (int e = lane; e < XT; e += 64) sX2[e] = 0.f;
   __syncthreads();
   STAMP(1);
 
   // ---- per-wave persistent state
-  constexpr int KA0 = W0C ? 0 : KB0;     // MFMA accumulators of dW0 (none when it runs on the VALU for certain)
-  f32x16 accW0[2][KA0 ? KA0 : 1];
+  f32x16 accW0[2][KB0];
   f32x16 accW1[2][2];
   // NBQ: hidden blocks whose backward this workgroup runs.  4 blocks x 2 outputs would need 256 registers for
   // the last layer's gradient accumulators alone, so that case is launched with gridDim.z = 2: every z runs
@@ -569,9 +563,9 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
   float dwlv[NBQ][NO];          // WLV: last-layer weight gradient of feature `lane` of block q
   float vdb0[NBQ], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
   // fan-in <= 4: dW0[lane][k] accumulates per lane on the VALU (row_sum32_dw4) instead of in accW0
-  const bool w0v = W0C || HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
+  const bool w0v = HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
   float dw0v[NBQ][4];
-  f32x16 dWL[WLV || DWF ? 1 : NBQ][NO][2];
+  f32x16 dWL[WLV ? 1 : NBQ][NO][2];
 #pragma unroll
   for (int qb = 0; qb < NBQ; ++qb) {
 #pragma unroll
@@ -584,7 +578,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
-    for (int kb = 0; kb < KA0; ++kb)
+    for (int kb = 0; kb < KB0; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accW0[nb][kb][r] = 0.f;
 #pragma unroll
@@ -596,7 +590,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
   for (int n = 0; n < NO; ++n) {
     dbL[n] = 0.f;
 #pragma unroll
-    for (int qb = 0; qb < (WLV || DWF ? 1 : NBQ); ++qb)
+    for (int qb = 0; qb < (WLV ? 1 : NBQ); ++qb)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -627,7 +621,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
   // The fetch is branch-free -- clamped addresses, idle lanes write a dummy LDS slot -- so that
   // the loads of strip i+1 stay in flight across strip i (a load under a branch makes the
   // compiler drain the vector-memory counter at the next join).
-  constexpr int XPF = W0C ? 2 : 6;     // 32 rows x fan-in <= 4: at most 128 elements
+  constexpr int XPF = 6;
   const int nelem = 32 * K0;
   int xoff[XPF];
   {
@@ -680,22 +674,6 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
   const int64_t sstride = (int64_t)gridDim.x * NW;
   int64_t strip = (int64_t)blockIdx.x * NW + wave;
   fetch(strip);
-  // STG (eight waves, 256 registers): values fetched a strip ahead would sit in registers across the whole strip
-  // body, where the compiler spills them (and waits for the load to do so).  They are parked in LDS instead, as
-  // soon as the forward's MFMAs have covered the load latency: x^T in the second x tile, the loss inputs in
-  // one 32-row slot each; the next strip picks them up from there.
-  float *sXc = sX, *sXn = sX2;       // x tile of this strip / of the next
-  auto stash = [&](float *xt) {
-#pragma unroll
-    for (int j = 0; j < XPF; ++j) xt[xoff[j]] = xr[j];
-    sIn[r32] = p_in0;                // (both lane halves hold, and write, the same value)
-#pragma unroll
-    for (int n = 0; n < NO; ++n) { sIn[(1 + n) * 32 + r32] = p_act[n]; sIn[(1 + NO + n) * 32 + r32] = p_olp[n]; }
-  };
-  if constexpr (STG) {
-    stash(sXc);
-    wave_lds_fence();
-  }
   PH_DECL
   for (; strip < nstrips; strip += sstride) {
     const int64_t row0 = strip << 5;
@@ -703,9 +681,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
     PH(5);
 
     // ---- x^T of the strip -> sX[k][row] (the strip's rows are contiguous in obs)
-    if constexpr (STG) {
-      // already there (stash); the loss inputs come from their slots
-    } else if (XP) {
+    if (XP) {
 #pragma unroll
       for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
     } else {
@@ -718,17 +694,10 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
         if (kk >= K0) { kk -= K0; ++rr; }
       }
     }
-    float ret, act[NO], olp[NO];
-    if constexpr (STG) {
-      ret = sIn[r32];
+    const float ret = p_in0, ad = p_in0;
+    float act[NO], olp[NO];
 #pragma unroll
-      for (int n = 0; n < NO; ++n) { act[n] = sIn[(1 + n) * 32 + r32]; olp[n] = sIn[(1 + NO + n) * 32 + r32]; }
-    } else {
-      ret = p_in0;
-#pragma unroll
-      for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
-    }
-    const float ad = ret;
+    for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
     fetch(strip + sstride);
     wave_lds_fence();
     PH(6);
@@ -746,7 +715,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
       for (int n = 0; n < NO; ++n) pacc[n] = 0.f;
 #pragma unroll
       for (int qb = 0; qb < HB; ++qb) {
-        fwd_layer0<LDW0>(h1q[RC ? 0 : qb], sXc, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
+        fwd_layer0<LDW0>(h1q[RC ? 0 : qb], sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
         if (RC) fwd_last_acc<NO>(pacc, h1q[0], sWL + qb * NO * 64, half);
       }
       PH(7);
@@ -757,7 +726,6 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
 #pragma unroll
           for (int qb = 0; qb < HB; ++qb) fwd_last_acc<NO>(pacc, h1q[qb], sWL + qb * NO * 64, half);
       }
-      if constexpr (STG) stash(sXn);     // the next strip's inputs have had the forward's MFMAs to arrive
       PH(8);
       fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
     }
@@ -773,7 +741,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
       if (half == 0) dbL[n] += gout[n];
 #pragma unroll
     for (int qb = 0; qb < NBQ; ++qb) {    // one pass per 64-wide block of the hidden layer (HB > 1: D == 2)
-    if (RC) fwd_layer0<LDW0>(h1q[0], sXc, sW0 + (qb0 + qb) * 64 * LDW0, sB + (qb0 + qb) * 64, ksteps0, half, r32);
+    if (RC) fwd_layer0<LDW0>(h1q[0], sX, sW0 + (qb0 + qb) * 64 * LDW0, sB + (qb0 + qb) * 64, ksteps0, half, r32);
     const f32x16 (&hl)[2] = D == 3 ? h2 : h1q[RC ? 0 : qb];
     const float *sWLq = sWL + (qb0 + qb) * NO * 64;
     if constexpr (WLV) {
@@ -785,15 +753,6 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
       }
       wave_lds_fence();
       rows_dwl<NO>(sH + lane * LDT, sGo, dwlv[qb]);
-    } else if constexpr (DWF) {
-      // the same through the g tile, before the layer gradient takes it (LDS operations of a wave execute in order)
-      put_tile(sG, hl, half, r32);
-      if (half == 0) {
-#pragma unroll
-        for (int n = 0; n < NO; ++n) sGo[n * LDT + r32] = gout[n];
-      }
-      wave_lds_fence();
-      rows_dwl<NO>(sG + lane * LDT, sGo, dwlv[qb]);
     }
     // ---- last layer backward (VALU): dWL, dbL partials; g = (WL^T gout) * (hl > 0)
     f32x16 g[2];
@@ -809,7 +768,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
           t[1] = fmaf(w4.y, gout[n], t[1]);
           t[2] = fmaf(w4.z, gout[n], t[2]);
           t[3] = fmaf(w4.w, gout[n], t[3]);
-          if constexpr (!WLV && !DWF) {
+          if constexpr (!WLV) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dWL[qb][n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[qb][n][kb][4 * q + i]);
           }
@@ -824,42 +783,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
       put_tile(sG, g, half, r32);
       // rows in the order (j, half, i) -> row 8j + 4half + i: a lane's four steps are one 16 B read
       const float *ga = sG + r32 * LDT + 4 * half, *ha = sH + r32 * LDT + 4 * half;
-      if constexpr (HT) {
-        // Eight waves, 256 registers each: the input gradient comes first (g is in registers), h1 is not held from
-        // the forward but recomputed after it (layer 0 over a fan-in <= 4 is four MFMAs), and its transpose goes
-        // through LDS one 32-feature half at a time (a wave's LDS operations execute in issue order: the second
-        // half's writes follow the first half's reads without a wait)
-        wave_lds_fence();
-        vdb1 += row_sum32(sG + lane * LDT);
-        f32x16 t[2];
-        bwd_dx1(t, g, sW1T, half, r32);
-        f32x16 h1r[2];
-        fwd_layer0<LDW0>(h1r, sXc, sW0, sB, ksteps0, half, r32);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sH[feat(r, half) * LDT + r32] = h1r[kb][r];
-          wave_lds_fence();
-          float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), x0 = ld4(ha);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float4 ng0 = g0, ng1 = g1, nx0 = x0;
-            if (j + 1 < 4) {
-              ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
-              nx0 = ld4(ha + 8 * (j + 1));
-            }
-            issue_fence();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              accW1[0][kb] = MFMA(f4(g0, i), f4(x0, i), accW1[0][kb]);
-              accW1[1][kb] = MFMA(f4(g1, i), f4(x0, i), accW1[1][kb]);
-            }
-            g0 = ng0; g1 = ng1; x0 = nx0;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) g[kb][r] = h1r[kb][r] > 0.f ? t[kb][r] : 0.f;
-        }
-      } else {
+      {
         put_tile(sH, h1, half, r32);
         wave_lds_fence();
         {
@@ -897,10 +821,10 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
     put_tile(sG, g, half, r32);
     wave_lds_fence();
     PH(9);
-    if (W0C || w0v) {
-      vdb0[qb] += row_sum32_dw4(sG + lane * LDT, sXc, dw0v[qb]);
-    } else if constexpr (!W0C) {
-      const float *ga = sG + r32 * LDT + 4 * half, *xa = sXc + r32 * LDT + 4 * half;
+    if (w0v) {
+      vdb0[qb] += row_sum32_dw4(sG + lane * LDT, sX, dw0v[qb]);
+    } else {
+      const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
       float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), xv[KB0];
 #pragma unroll
       for (int kb = 0; kb < KB0; ++kb) xv[kb] = ld4(xa + kb * 32 * LDT);
@@ -928,9 +852,8 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
       }
       vdb0[0] += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
     }
-    wave_lds_fence();     // the next block / strip overwrites sG (and sXc)
+    wave_lds_fence();     // the next block / strip overwrites sG (and sX)
     }                     // hidden blocks
-    if constexpr (STG) { float *t = sXc; sXc = sXn; sXn = t; }
     PH(3);
   }
   PH_OUT;
@@ -950,7 +873,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
     for (int qb = 0; qb < NBQ; ++qb)
 #pragma unroll
       for (int n = 0; n < NO; ++n) {
-        if constexpr (WLV || DWF) {
+        if constexpr (WLV) {
           vec_wl[qb][n] = dwlv[qb][n];           // already per feature
         } else {
           put_tile(sG, dWL[qb][n], half, r32);
@@ -998,7 +921,7 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
       }
     }
   };
-  if constexpr (!W0C) {
+  {
     auto acc0 = [&](int nb, int kb) -> f32x16 & { return accW0[nb][kb < KB0 ? kb : 0]; };
     if (!w0v) flush_tile(acc0, KB0, H1, K0, a.poff[0]);     // (workgroup-uniform)
   }
@@ -1063,23 +986,28 @@ __global__ __launch_bounds__(64 * NW) void k_ac_learn(LearnArgs P) {
 // Role-split variant of k_ac_learn for two hidden layers (<= 64 wide) over a fan-in <= 4 (PPO / A2C on Pendulum- or
 // CartPole-sized observations): 512 threads, and the two waves that share a SIMD (w and w + 4) share every strip.
 //
-// Why.  v_mfma_f32_32x32x2_f32 holds ITS OWN wave for its 64 cycles -- a VALU or LDS instruction behind it adds its
-// full issue time -- but another wave on the same SIMD issues VALU work at full rate meanwhile
-// (tools/mfma_valu_probe.hip: 64.1 -> 129 cycles per MFMA with 16 v_fma behind each in one wave; 64.2 cycles with the
-// same v_fma in a partner wave).  One wave per SIMD therefore pays MFMA + VALU (k_ac_learn: 20.5 k cycles per strip
-// for 12.5 k of MFMA).  Two symmetric waves per SIMD at 256 registers each do not fit this step without spills (64
-// accumulators of dW1 per wave).  So the pair splits the STEP instead of the strips:
-//   wave A (w < 4): the dependent chain -- forward, loss, last layer backward, the input gradient of layer 1, the
-//     ReLU masks -- and the transposing tile writes; it holds no weight-gradient tile;
-//   wave B (w + 4): everything that only reads A's tiles -- the 64 MFMAs of dW1, the bias-gradient row sums, the
-//     layer-0 weight gradient -- and so holds the 64 dW1 accumulators.
-// A's VALU stretches run under B's MFMAs and B's under A's.  Hand-off through one set of LDS tiles per pair and four
-// counters (LDS operations of the CU execute in issue order, so a counter written after a tile is seen after it):
-//   pub[0] strips whose g2 / h1^T tiles are written (A)    pub[2] strips whose g2 / h1^T tiles B has consumed
-//   pub[1] strips whose g1 tile is written (A)             pub[3] strips whose g1 / x^T tiles B has consumed
+// Why (tools/mfma_valu_probe.hip).  v_mfma_f32_32x32x2_f32 holds ITS OWN wave for its 64 cycles: a VALU or LDS
+// instruction behind it adds its full issue time (16 v_fma behind each MFMA: 64 -> 129 cycles per MFMA).  One wave
+// per SIMD therefore pays MFMA + VALU + every LDS round trip (k_ac_learn: 20.5 k cycles per strip for 12.5 k of MFMA).
+// A second wave on the SIMD does get work done meanwhile -- LDS traffic at full rate, and about two VALU
+// instructions per partner MFMA (26-28 cycles each beside an MFMA stream, whatever their independence) -- but two
+// symmetric waves at 256 registers each do not fit this step without spills (64 dW1 accumulators per wave).  So the
+// pair splits the STEP instead of the strips:
+//   wave A (w < 4): forward, loss, last layer backward, the ReLU mask of layer 1, the transposing writes of the
+//     g2 and h1^T tiles, db1; it holds no weight-gradient tile;
+//   wave B (w + 4): everything that only needs those tiles -- dW1 (64 MFMAs), the input gradient of layer 1 (64
+//     MFMAs: nothing A computes depends on it), its mask, the g1 tile, db0 and dW0 -- with the 64 dW1 accumulators.
+// Each wave's LDS round trips, waits and part of its VALU work run under the other's MFMAs.  Hand-off through one
+// set of LDS tiles per pair and counters (LDS operations of the CU execute in issue order, so a counter written
+// after a tile is seen after it):
+//   pub[0] strips whose g2 / h1^T tiles are written (A)
+//   pub[2] strips whose g2 / h1^T tiles B has read (B reads them into registers at once, so A can write the next)
+//   pub[3] strips whose x^T tile B is done with (three x tiles in rotation: A never waits on this one)
 // Every wait is bounded (a pair that lost its partner finishes with wrong numbers rather than hanging the GPU).
 // Strip assignment, operation order and partial-sum order are those of k_ac_learn<3, 1, NO, true> (pair p = its wave
-// p), so the two kernels give the same bits.
+// p), so the two kernels give the same bits.  Measured with the in-kernel trace (tools/learn_pair_trace.py): the two
+// waves' MFMA streams do not interleave -- whichever streams keeps the pipe (wave priorities change nothing) -- and
+// the period is B's 128 MFMAs + A's 68 + about 3 k cycles in which neither has one to issue.
 __device__ __forceinline__ void pair_wait(const int *ctr, int want) {
   for (int spin = 0; spin < (1 << 20); ++spin) {
     const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1103,7 +1031,7 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   constexpr int OFF_W1 = OFF_W0 + 64 * LDW0;
   constexpr int OFF_W1T = OFF_W1 + 64 * LDW;
   constexpr int OFF_T = OFF_W1T + 64 * LDW;
-  constexpr int PT = 2 * XT + 3 * 64 * LDT + 8;       // per pair: two x tiles, g2, h1^T, g1 tiles, the counters
+  constexpr int PT = 3 * XT + 3 * 64 * LDT + 8;       // per pair: three x tiles, g2, h1^T, g1 tiles, the counters
   __shared__ __align__(16) float smem[OFF_T + 4 * PT];
   float *const sB = smem + OFF_B, *const sWL = smem + OFF_WL, *const sW0 = smem + OFF_W0, *const sW1 = smem + OFF_W1,
                *const sW1T = smem + OFF_W1T, *const sT = smem + OFF_T;
@@ -1114,19 +1042,31 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5,
             r32 = lane & 31;
   const int pair = wave & 3;
+#ifdef TRL_TUNING
+  const bool roleA = (P.tune_prio & 16) ? wave >= 4 : wave < 4;      // A/B runs of tools/: bit 4 swaps the roles,
+  const int dynp = roleA ? (P.tune_prio & 3) : ((P.tune_prio >> 2) & 3);   // bits 1:0 / 3:2: priority of A's / B's matrix phases
+#define MATRIX_PHASE() do { if (dynp == 1) __builtin_amdgcn_s_setprio(1); else if (dynp == 2) __builtin_amdgcn_s_setprio(2); else if (dynp == 3) __builtin_amdgcn_s_setprio(3); } while (0)
+#define VECTOR_PHASE() do { if (dynp) __builtin_amdgcn_s_setprio(0); } while (0)
+  const bool hold = (P.tune_prio & 32) != 0;                          // bit 5: B's stream waits for A's forward
+  const bool late = (P.tune_prio & 64) != 0;                          // bit 6: tiles released after B's MFMAs
+#else
   const bool roleA = wave < 4;
+  constexpr bool hold = false, late = false;
+#define MATRIX_PHASE()
+#define VECTOR_PHASE()
+#endif
   const int K0 = a.dims[0], H1 = a.dims[1], HL = a.dims[2], NOr = a.dims[3];
   const int64_t B = P.B;
   const int A = P.A;
 
   stage_weights<D, LDW0, NO, true, 1, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
-  float *sXp = sT + pair * PT;          // [2][XT]     x^T of the strip, alternating
-  float *sG2 = sXp + 2 * XT;            // [64][LDT]   gradient w.r.t. layer 1's pre-activation
+  float *sXp = sT + pair * PT;          // [3][XT]     x^T of the strip, in rotation (see wave A's loop)
+  float *sG2 = sXp + 3 * XT;            // [64][LDT]   gradient w.r.t. layer 1's pre-activation
   float *sH1 = sG2 + 64 * LDT;          // [64][LDT]   h1^T
   float *sG1 = sH1 + 64 * LDT;          // [64][LDT]   gradient w.r.t. layer 0's pre-activation
   int *pub = (int *)(sG1 + 64 * LDT);   // [4]         hand-off counters
   if (roleA) {
-    for (int e = lane; e < 2 * XT; e += 64) sXp[e] = 0.f;   // rows >= K0 stay zero for good
+    for (int e = lane; e < 3 * XT; e += 64) sXp[e] = 0.f;   // rows >= K0 stay zero for good
     if (lane < 8) pub[lane] = 0;
   }
   __syncthreads();
@@ -1139,8 +1079,8 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   // partials; B: the dW1 accumulators) is declared inside its role's branch, so that it takes no registers in the
   // other role's loop; each branch parks it in LDS before the common code.  Both branches execute the same number
   // of workgroup barriers.
-  float vdb0 = 0.f, vdb1 = 0.f, dw0v[4] = {0.f, 0.f, 0.f, 0.f};      // B
-  float vec_wl[NO], sc[2 + 2 * NO];                                  // A
+  float vdb0 = 0.f, dw0v[4] = {0.f, 0.f, 0.f, 0.f};                  // B
+  float vdb1 = 0.f, vec_wl[NO], sc[2 + 2 * NO];                      // A
 #pragma unroll
   for (int n = 0; n < NO; ++n) vec_wl[n] = 0.f;
 #pragma unroll
@@ -1220,8 +1160,13 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
     for (int it = 0; strip < nstrips; strip += sstride, ++it) {
       const int64_t row0 = strip << 5;
       const bool valid = row0 + r32 < B;
-      // x^T of the strip (B read this buffer for strip it - 2; the g1 wait of strip it - 1 has covered that)
-      float *sX = sXp + (it & 1) * XT;
+      // x^T of the strip, in the buffer B read for the layer-0 gradient of strip it - 3.  Three buffers, so that
+      // this wave never waits for that gradient: B ran it before the dX1 of strip it - 2, which the tile wait of
+      // strip it - 1 has already seen (with two buffers the pipe idled while B finished strip it - 2's layer 0)
+      TRACE(0);
+      const int xb = it % 3;
+      float *sX = sXp + xb * XT;
+      pair_wait(pub + 3, it - 2);
 #pragma unroll
       for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
       const float ret = p_in0, ad = p_in0;
@@ -1233,8 +1178,13 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
 
       f32x16 h1[2], h2[2];
       float out[NO];
+      TRACE(1);
+      MATRIX_PHASE();
       fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
       fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+      if (hold && lane == 0) __hip_atomic_store(pub + 1, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      VECTOR_PHASE();
+      TRACE(2);
       fwd_last<NO>(out, h2, sWL, sB + 128, half);
 
       float gout[NO];
@@ -1264,24 +1214,27 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
           for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = h2[kb][4 * q + i] > 0.f ? t[i] : 0.f;
         }
 
-      // publish g2 and h1^T (B has consumed the previous strip's)
-      pair_wait(pub + 2, it);
-      put_tile(sG2, g, half, r32);
-      put_tile(sH1, h1, half, r32);
-      pair_post(pub + 0, it + 1, lane);
-
-      // layer 1 backward, input side, and its mask
-      f32x16 t[2];
-      bwd_dx1(t, g, sW1T, half, r32);
+      // (pin the arithmetic above before the wait: beside the partner's MFMA stream, which starts about when the
+      // wait ends, dependent VALU work runs several times slower -- tools/mfma_valu_probe.hip, k_cmp -- while the
+      // plain LDS writes below do not care)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[kb][r] = h1[kb][r] > 0.f ? t[kb][r] : 0.f;
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(g[kb][r]));
+      // publish g2 and h1^T (B has consumed the previous strip's)
+      TRACE(3);
+      pair_wait(pub + 2, it);
+      TRACE(4);
+      put_tile(sG2, g, half, r32);
+      TRACE(7);
+      put_tile(sH1, h1, half, r32);
+      pair_post(pub + 0, it + 1, lane);
+      TRACE(5);
 
-      pair_wait(pub + 3, it);
-      put_tile(sG1, g, half, r32);
-      pair_post(pub + 1, it + 1, lane);
+      vdb1 += row_sum32(sG2 + lane * LDT);     // db1[lane]: the row of the tile this wave has just written
+      TRACE(6);
     }
+    if (lane == 0) __hip_atomic_store(pub + 1, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // no forward left to wait for
     __syncthreads();      // (1) every pair is through its strips: the pair regions are free
     // per-lane partial vectors dWL[n] -> per-feature sums over the wave's 32 rows, through a tile behind B's
     float *tr = mine + 64 * 64;
@@ -1312,35 +1265,67 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
         for (int r = 0; r < 16; ++r) accW1[nb][kb][r] = 0.f;
     const float *ga = sG2 + r32 * LDT + 4 * half, *ha = sH1 + r32 * LDT + 4 * half;
     for (int it = 0; strip < nstrips; strip += sstride, ++it) {
-      // dW1 += g2 h1^T: rows in the order (j, half, i) -> row 8j + 4half + i, a lane's four steps are one 16 B read
+      TRACE(0);
       pair_wait(pub + 0, it + 1);
-      {
-        float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), x0 = ld4(ha), x1 = ld4(ha + 32 * LDT);
+      TRACE(1);
+      // Everything this strip needs from the two tiles is read up front, into registers, and the tiles handed back:
+      // A writes the next strip's while this wave's 128 MFMAs run (held for the 128 MFMAs, the single set of tiles
+      // put A's tile writes and this wave's vector phase in series with them).
+      //   h1 and g2 in the accumulator layout (lane = row, register r = feature feat(r, half)): the ReLU mask of
+      //   layer 0 and the B operand of the input-gradient product
+      f32x16 hm[2], gB[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float4 ng0 = g0, ng1 = g1, nx0 = x0, nx1 = x1;
-          if (j + 1 < 4) {
-            ng0 = ld4(ga + 8 * (j + 1)); ng1 = ld4(ga + 32 * LDT + 8 * (j + 1));
-            nx0 = ld4(ha + 8 * (j + 1)); nx1 = ld4(ha + 32 * LDT + 8 * (j + 1));
-          }
-          issue_fence();
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            accW1[0][0] = MFMA(f4(g0, i), f4(x0, i), accW1[0][0]);
-            accW1[0][1] = MFMA(f4(g0, i), f4(x1, i), accW1[0][1]);
-            accW1[1][0] = MFMA(f4(g1, i), f4(x0, i), accW1[1][0]);
-            accW1[1][1] = MFMA(f4(g1, i), f4(x1, i), accW1[1][1]);
-          }
-          g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
+        for (int r = 0; r < 16; ++r) {
+          hm[kb][r] = sH1[(kb * 32 + feat(r, half)) * LDT + r32];
+          gB[kb][r] = sG2[(kb * 32 + feat(r, half)) * LDT + r32];
         }
+      //   the operands of dW1 += g2 h1^T: rows in the order (j, half, i) -> row 8j + 4half + i, a lane's four steps
+      //   are one 16 B read
+      float4 G0[4], G1[4], X0[4], X1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        G0[j] = ld4(ga + 8 * j); G1[j] = ld4(ga + 32 * LDT + 8 * j);
+        X0[j] = ld4(ha + 8 * j); X1[j] = ld4(ha + 32 * LDT + 8 * j);
       }
-      vdb1 += row_sum32(sG2 + lane * LDT);
-      pair_post(pub + 2, it + 1, lane);
-
+      if (!late) pair_post(pub + 2, it + 1, lane);         // (waits for the reads above)
+      // A wave that streams MFMAs keeps the SIMD's matrix pipe: its partner's MFMAs (and what follows them in
+      // program order) wait until the stream ends.  So the order of the two streams is chosen here, not left to
+      // the race: A's forward of the NEXT strip goes first (it needs nothing from this wave), and this wave's 128
+      // MFMAs follow it while A runs its loss, last layer and tile writes -- A's tiles are then ready when this
+      // stream ends.  The other order leaves the pipe idle while A finishes the strip this wave waits for.
+      if (hold) pair_wait(pub + 1, it + 2);
+      TRACE(2);
+      MATRIX_PHASE();
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          accW1[0][0] = MFMA(f4(G0[j], i), f4(X0[j], i), accW1[0][0]);
+          accW1[0][1] = MFMA(f4(G0[j], i), f4(X1[j], i), accW1[0][1]);
+          accW1[1][0] = MFMA(f4(G1[j], i), f4(X0[j], i), accW1[1][0]);
+          accW1[1][1] = MFMA(f4(G1[j], i), f4(X1[j], i), accW1[1][1]);
+        }
+      // layer 1 backward, input side: t^T = W1^T g2^T (A holds g2 in registers too and would run this product
+      // itself; here it costs A nothing), then the mask: g1 = t * (h1 > 0)
+      f32x16 t[2];
+      TRACE(3);
+      bwd_dx1(t, gB, sW1T, half, r32);
+      VECTOR_PHASE();
+      if (late) pair_post(pub + 2, it + 1, lane);
+      TRACE(4);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[kb][r] = hm[kb][r] > 0.f ? t[kb][r] : 0.f;
+      put_tile(sG1, t, half, r32);
+      wave_lds_fence();
+      TRACE(5);
       // layer 0: db0 and dW0 (VALU, fan-in <= 4)
-      pair_wait(pub + 1, it + 1);
-      vdb0 += row_sum32_dw4(sG1 + lane * LDT, sXp + (it & 1) * XT, dw0v);
+      vdb0 += row_sum32_dw4(sG1 + lane * LDT, sXp + (it % 3) * XT, dw0v);
       pair_post(pub + 3, it + 1, lane);
+      TRACE(6);
     }
     __syncthreads();      // (1)
 #pragma unroll
@@ -1373,9 +1358,9 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
     }
 #pragma unroll
     for (int n = 0; n < NO; ++n) vsum[(pair * VS + 2 + n) * 64 + lane] = vec_wl[n];
+    vsum[(pair * VS + 1) * 64 + lane] = vdb1;
   } else {
     vsum[(pair * VS + 0) * 64 + lane] = vdb0;
-    vsum[(pair * VS + 1) * 64 + lane] = vdb1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) vsum[(pair * VS + 2 + NO + k) * 64 + lane] = dw0v[k];
   }
@@ -1681,9 +1666,9 @@ int fill_dst(const char *fn, const NetArgs &a, float *const *pg, GradDst *gd) {
   return TRL_OK;
 }
 
-inline int learn_wgs(int64_t B, int nw) {
+inline int learn_wgs(int64_t B) {
   // one workgroup per CU over both networks: 128 per network, fewer when the batch is small
-  const int64_t need = trl_cdiv(trl_cdiv(B, 32), nw);
+  const int64_t need = trl_cdiv(trl_cdiv(B, 32), 4);
   return (int)(need < 128 ? need : 128);
 }
 
@@ -1734,16 +1719,13 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   P.pstride = pstride_of(P.net[0].nparams, P.net[1].nparams);
   // two hidden layers over a fan-in <= 4 and enough strips for 2 x 1024 waves: the eight-wave variant
   const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
-  bool w8 = critic->depth == 3 && critic->dims[0] <= 4 && A <= 2 && B >= 8 * 32 * 128;
-  bool pairk = true;       // role-split pairs (k_ac_learn_pair); false: the symmetric eight-wave variant (A == 1)
+  // two hidden layers over a fan-in <= 4 and enough strips to keep 1024 wave pairs busy: the role-split kernel
+  bool pairk = critic->depth == 3 && critic->dims[0] <= 4 && A <= 2 && B >= 8 * 32 * 128;
 #ifdef TRL_TUNING
-  if (const char *e = getenv("TRL_LEARN_NW")) {     // A/B runs of tools/ only: 4, 8 (symmetric), 9 (pairs)
-    w8 = w8 && atoi(e) >= 8;
-    pairk = atoi(e) != 8;
-  }
+  if (const char *e = getenv("TRL_LEARN_NW")) pairk = pairk && atoi(e) != 4;     // A/B runs of tools/ only
+  if (const char *e = getenv("TRL_LEARN_PRIO")) P.tune_prio = atoi(e);
 #endif
-  if (!pairk) w8 = w8 && A == 1;
-  const int nwg = learn_wgs(B, w8 && !pairk ? 8 : 4);
+  const int nwg = learn_wgs(B);
   ReduceArgs R{};
   R.ws = (const float *)ws; R.nwg = nwg; R.pstride = P.pstride;
   R.nparams[0] = P.net[0].nparams; R.nparams[1] = P.net[1].nparams;
@@ -1770,7 +1752,7 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   }
 
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)nwg, 2), block(w8 ? 512 : 256);
+  const dim3 grid((unsigned)nwg, 2), block(pairk ? 512 : 256);
   const int D = critic->depth, KB0 = critic->dims[0] <= 32 ? 1 : 2, NOv = A <= 1 ? 1 : (A <= 2 ? 2 : 4);
   const bool xp = critic->dims[0] <= 12;
 #define TRL_LEARN_CASE(d, kb, no)                                                                  \
@@ -1778,10 +1760,9 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
     if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_learn<d, kb, no, kb == 1>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_learn<d, kb, no, false>), grid, block, 0, st, P);               \
   }
-  if (w8) {
-    if (pairk && NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair<1>), grid, block, 0, st, P);
-    else if (pairk) hipLaunchKernelGGL((k_ac_learn_pair<2>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((k_ac_learn<3, 1, 1, true, 1, 8>), grid, block, 0, st, P);
+  if (pairk) {
+    if (NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair<1>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_ac_learn_pair<2>), grid, block, 0, st, P);
   } else if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
     // (4 blocks x 2 outputs: the last layer's weight gradient is accumulated per feature from LDS tiles, WLV)
     TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
