@@ -39,6 +39,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDT = 36;       // row stride of the [feature][row] transpose tiles (16 B rows: ds_read_b128 operands)
 constexpr int LDW = 68;       // row stride of the 64 x 64 weight tiles
@@ -1000,14 +1001,15 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 // Each wave's LDS round trips, waits and part of its VALU work run under the other's MFMAs.  Hand-off through one
 // set of LDS tiles per pair and counters (LDS operations of the CU execute in issue order, so a counter written
 // after a tile is seen after it):
-//   pub[0] strips whose g2 / h1^T tiles are written (A)
+//   pub[0] strips whose g2 tile is written, pub[1] strips whose h1^T tile is written (A)
 //   pub[2] strips whose g2 / h1^T tiles B has read (B reads them into registers at once, so A can write the next)
-//   pub[3] strips whose x^T tile B is done with (three x tiles in rotation: A never waits on this one)
+//   pub[3] strips whose x^T tile B is done with (four x tiles in rotation: A never waits on this one)
 // Every wait is bounded (a pair that lost its partner finishes with wrong numbers rather than hanging the GPU).
-// Strip assignment, operation order and partial-sum order are those of k_ac_learn<3, 1, NO, true> (pair p = its wave
-// p), so the two kernels give the same bits.  Measured with the in-kernel trace (tools/learn_pair_trace.py): the two
-// waves' MFMA streams do not interleave -- whichever streams keeps the pipe (wave priorities change nothing) -- and
-// the period is B's 128 MFMAs + A's 68 + about 3 k cycles in which neither has one to issue.
+// Strip assignment and partial-sum order are those of k_ac_learn<3, 1, NO, true> (pair p = its wave p); all results
+// but the layer-0 gradients (summed row by row on the 4x4 MFMA here, in four interleaved partial sums there) are the
+// same bits.  Measured with the in-kernel trace (tools/learn_pair_trace.py): the two waves' MFMA streams do not
+// interleave -- whichever streams keeps the pipe (wave priorities change nothing) -- and the period is B's 128 MFMAs
+// + A's 68 + about 3 k cycles of dependent LDS round trips at the strip boundary in which neither has one to issue.
 __device__ __forceinline__ void pair_wait(const int *ctr, int want) {
   for (int spin = 0; spin < (1 << 20); ++spin) {
     const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1031,7 +1033,8 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   constexpr int OFF_W1 = OFF_W0 + 64 * LDW0;
   constexpr int OFF_W1T = OFF_W1 + 64 * LDW;
   constexpr int OFF_T = OFF_W1T + 64 * LDW;
-  constexpr int PT = 3 * XT + 3 * 64 * LDT + 8;       // per pair: three x tiles, g2, h1^T, g1 tiles, the counters
+  constexpr int NXB = 4;                              // x tiles in rotation (see wave A's loop)
+  constexpr int PT = NXB * XT + 3 * 64 * LDT + 8;     // per pair: the x tiles, g2, h1^T, g1 tiles, the counters
   __shared__ __align__(16) float smem[OFF_T + 4 * PT];
   float *const sB = smem + OFF_B, *const sWL = smem + OFF_WL, *const sW0 = smem + OFF_W0, *const sW1 = smem + OFF_W1,
                *const sW1T = smem + OFF_W1T, *const sT = smem + OFF_T;
@@ -1047,11 +1050,10 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   const int dynp = roleA ? (P.tune_prio & 3) : ((P.tune_prio >> 2) & 3);   // bits 1:0 / 3:2: priority of A's / B's matrix phases
 #define MATRIX_PHASE() do { if (dynp == 1) __builtin_amdgcn_s_setprio(1); else if (dynp == 2) __builtin_amdgcn_s_setprio(2); else if (dynp == 3) __builtin_amdgcn_s_setprio(3); } while (0)
 #define VECTOR_PHASE() do { if (dynp) __builtin_amdgcn_s_setprio(0); } while (0)
-  const bool hold = (P.tune_prio & 32) != 0;                          // bit 5: B's stream waits for A's forward
-  const bool late = (P.tune_prio & 64) != 0;                          // bit 6: tiles released after B's MFMAs
+  const bool hold = !(P.tune_prio & 32);                              // bit 5: no stream ordering
 #else
   const bool roleA = wave < 4;
-  constexpr bool hold = false, late = false;
+  constexpr bool hold = false;
 #define MATRIX_PHASE()
 #define VECTOR_PHASE()
 #endif
@@ -1060,13 +1062,17 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   const int A = P.A;
 
   stage_weights<D, LDW0, NO, true, 1, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
-  float *sXp = sT + pair * PT;          // [3][XT]     x^T of the strip, in rotation (see wave A's loop)
-  float *sG2 = sXp + 3 * XT;            // [64][LDT]   gradient w.r.t. layer 1's pre-activation
+  float *sXp = sT + pair * PT;          // [NXB][XT]   x^T of the strip, in rotation
+  float *sG2 = sXp + NXB * XT;            // [64][LDT]   gradient w.r.t. layer 1's pre-activation
   float *sH1 = sG2 + 64 * LDT;          // [64][LDT]   h1^T
   float *sG1 = sH1 + 64 * LDT;          // [64][LDT]   gradient w.r.t. layer 0's pre-activation
   int *pub = (int *)(sG1 + 64 * LDT);   // [4]         hand-off counters
   if (roleA) {
-    for (int e = lane; e < 3 * XT; e += 64) sXp[e] = 0.f;   // rows >= K0 stay zero for good
+    for (int e = lane; e < NXB * XT; e += 64) sXp[e] = 0.f;   // rows >= K0 stay zero for good ...
+    if (K0 < 4 && lane < 32) {                                // ... but row 3, where there is room: ones (W0's column 3
+#pragma unroll                                                 // is zero, so the forward does not see them), which make
+      for (int t = 0; t < NXB; ++t) sXp[t * XT + 3 * LDT + lane] = 1.f;   // the layer-0 bias gradient a column of dW0
+    }
     if (lane < 8) pub[lane] = 0;
   }
   __syncthreads();
@@ -1079,7 +1085,8 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   // partials; B: the dW1 accumulators) is declared inside its role's branch, so that it takes no registers in the
   // other role's loop; each branch parks it in LDS before the common code.  Both branches execute the same number
   // of workgroup barriers.
-  float vdb0 = 0.f, dw0v[4] = {0.f, 0.f, 0.f, 0.f};                  // B
+  float vdb0 = 0.f;                                                  // B
+  f32x4 dw0m = {0.f, 0.f, 0.f, 0.f};                                 // B: dW0[4 (lane / 4) + i][lane % 4] in element i
   float vdb1 = 0.f, vec_wl[NO], sc[2 + 2 * NO];                      // A
 #pragma unroll
   for (int n = 0; n < NO; ++n) vec_wl[n] = 0.f;
@@ -1136,12 +1143,12 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
       in_olp[n] = ppo_actor ? P.old_logp + (n < A ? n : 0) : in0;
     }
     float xr[XPF], p_in0 = 0.f, p_act[NO], p_olp[NO];
-    auto fetch = [&](int64_t st) {      // (st is wave-uniform: scalar bases, 32-bit lane offsets)
+    // (st is wave-uniform: scalar bases, 32-bit lane offsets)
+    auto fetch_x = [&](int64_t st) {     // observations of a strip
       st = st < nstrips ? st : nstrips - 1;
       const int64_t row0 = st << 5;
       const int64_t left = B - row0;
       const int rows = (int)(left < 32 ? left : 32);
-      const int rl = r32 < rows ? r32 : rows - 1;
       const float *base = P.obs + row0 * K0;
       const int last = rows * K0 - 1;
 #pragma unroll
@@ -1149,6 +1156,13 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
         const int e = lane + 64 * j;
         xr[j] = base[e < last ? e : last];
       }
+    };
+    auto fetch_p = [&](int64_t st) {     // per-row loss inputs of a strip
+      st = st < nstrips ? st : nstrips - 1;
+      const int64_t row0 = st << 5;
+      const int64_t left = B - row0;
+      const int rows = (int)(left < 32 ? left : 32);
+      const int rl = r32 < rows ? r32 : rows - 1;
       p_in0 = (in0 + row0)[rl];
 #pragma unroll
       for (int n = 0; n < NO; ++n) {
@@ -1156,24 +1170,29 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
         p_olp[n] = (in_olp[n] + row0 * astr)[rl * astr];
       }
     };
-    fetch(strip);
+    // The x^T tile of strip it + 1 is written in the middle of strip it (its loads were issued a strip earlier), so
+    // that nothing stands between the end of B's MFMA stream and this wave's next forward but the loss inputs'
+    // copy.  NXB tiles in rotation: tile (it + 1) % NXB was last read by B's layer-0 gradient of strip it - 3,
+    // which the tile wait of strip it - 1 has long seen.
+    auto put_x = [&](int slot) {
+      float *sXw = sXp + (slot % NXB) * XT;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) sXw[xoff[j]] = xr[j];
+    };
+    fetch_x(strip);
+    fetch_p(strip);
+    put_x(0);
+    fetch_x(strip + sstride);
     for (int it = 0; strip < nstrips; strip += sstride, ++it) {
       const int64_t row0 = strip << 5;
       const bool valid = row0 + r32 < B;
-      // x^T of the strip, in the buffer B read for the layer-0 gradient of strip it - 3.  Three buffers, so that
-      // this wave never waits for that gradient: B ran it before the dX1 of strip it - 2, which the tile wait of
-      // strip it - 1 has already seen (with two buffers the pipe idled while B finished strip it - 2's layer 0)
       TRACE(0);
-      const int xb = it % 3;
-      float *sX = sXp + xb * XT;
-      pair_wait(pub + 3, it - 2);
-#pragma unroll
-      for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
+      float *sX = sXp + (it % NXB) * XT;      // written in the middle of the previous strip (put_x)
       const float ret = p_in0, ad = p_in0;
       float act[NO], olp[NO];
 #pragma unroll
       for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
-      fetch(strip + sstride);
+      fetch_p(strip + sstride);
       wave_lds_fence();
 
       f32x16 h1[2], h2[2];
@@ -1181,9 +1200,19 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
       TRACE(1);
       MATRIX_PHASE();
       fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+      // h1^T goes out as soon as it exists (B has read the previous strip's tiles long since): B picks it up while
+      // this wave is still in its forward, and only the g2 tile is left between the loss and B's MFMAs
+      TRACE(3);
+      pair_wait(pub + 2, it);
+      TRACE(4);
+      put_tile(sH1, h1, half, r32);
+      pair_post(pub + 1, it + 1, lane);
       fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
-      if (hold && lane == 0) __hip_atomic_store(pub + 1, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       VECTOR_PHASE();
+      pair_wait(pub + 3, it - 2);             // (never blocks: see put_x)
+      put_x(it + 1);
+      fetch_x(strip + 2 * sstride);
+      if (hold && lane == 0) __hip_atomic_store(pub + 4, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       TRACE(2);
       fwd_last<NO>(out, h2, sWL, sB + 128, half);
 
@@ -1207,34 +1236,28 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
             t[1] = fmaf(w4.y, gout[n], t[1]);
             t[2] = fmaf(w4.z, gout[n], t[2]);
             t[3] = fmaf(w4.w, gout[n], t[3]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dWL[n][kb][4 * q + i] = fmaf(gout[n], h2[kb][4 * q + i], dWL[n][kb][4 * q + i]);
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = h2[kb][4 * q + i] > 0.f ? t[i] : 0.f;
         }
-
-      // (pin the arithmetic above before the wait: beside the partner's MFMA stream, which starts about when the
-      // wait ends, dependent VALU work runs several times slower -- tools/mfma_valu_probe.hip, k_cmp -- while the
-      // plain LDS writes below do not care)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(g[kb][r]));
-      // publish g2 and h1^T (B has consumed the previous strip's)
-      TRACE(3);
-      pair_wait(pub + 2, it);
-      TRACE(4);
-      put_tile(sG2, g, half, r32);
+      // publish g2: the last thing B's MFMAs wait for
       TRACE(7);
-      put_tile(sH1, h1, half, r32);
+      put_tile(sG2, g, half, r32);
       pair_post(pub + 0, it + 1, lane);
       TRACE(5);
 
+      // off the critical path (B's MFMA stream has started: VALU work here runs at 26-28 cycles per instruction,
+      // tools/mfma_valu_probe.hip, but this wave's next forward waits for that stream to end anyway)
+#pragma unroll
+      for (int n = 0; n < NO; ++n)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dWL[n][kb][r] = fmaf(gout[n], h2[kb][r], dWL[n][kb][r]);
       vdb1 += row_sum32(sG2 + lane * LDT);     // db1[lane]: the row of the tile this wave has just written
       TRACE(6);
     }
-    if (lane == 0) __hip_atomic_store(pub + 1, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // no forward left to wait for
+    if (lane == 0) __hip_atomic_store(pub + 4, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // no forward left to wait for
     __syncthreads();      // (1) every pair is through its strips: the pair regions are free
     // per-lane partial vectors dWL[n] -> per-feature sums over the wave's 32 rows, through a tile behind B's
     float *tr = mine + 64 * 64;
@@ -1265,37 +1288,39 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
         for (int r = 0; r < 16; ++r) accW1[nb][kb][r] = 0.f;
     const float *ga = sG2 + r32 * LDT + 4 * half, *ha = sH1 + r32 * LDT + 4 * half;
     for (int it = 0; strip < nstrips; strip += sstride, ++it) {
-      TRACE(0);
-      pair_wait(pub + 0, it + 1);
-      TRACE(1);
       // Everything this strip needs from the two tiles is read up front, into registers, and the tiles handed back:
       // A writes the next strip's while this wave's 128 MFMAs run (held for the 128 MFMAs, the single set of tiles
-      // put A's tile writes and this wave's vector phase in series with them).
-      //   h1 and g2 in the accumulator layout (lane = row, register r = feature feat(r, half)): the ReLU mask of
-      //   layer 0 and the B operand of the input-gradient product
+      // put A's tile writes and this wave's vector phase in series with them).  h1^T comes first, while A is still
+      // in its forward:
+      //   h1 in the accumulator layout (lane = row, register r = feature feat(r, half)): the ReLU mask of layer 0;
+      //   as rows in the order (j, half, i) -> row 8j + 4half + i (a lane's four steps are one 16 B read): the B
+      //   operand of dW1 += g2 h1^T
+      TRACE(0);
+      pair_wait(pub + 1, it + 1);
       f32x16 hm[2], gB[2];
+      float4 G0[4], G1[4], X0[4], X1[4];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          hm[kb][r] = sH1[(kb * 32 + feat(r, half)) * LDT + r32];
-          gB[kb][r] = sG2[(kb * 32 + feat(r, half)) * LDT + r32];
-        }
-      //   the operands of dW1 += g2 h1^T: rows in the order (j, half, i) -> row 8j + 4half + i, a lane's four steps
-      //   are one 16 B read
-      float4 G0[4], G1[4], X0[4], X1[4];
+        for (int r = 0; r < 16; ++r) hm[kb][r] = sH1[(kb * 32 + feat(r, half)) * LDT + r32];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        G0[j] = ld4(ga + 8 * j); G1[j] = ld4(ga + 32 * LDT + 8 * j);
-        X0[j] = ld4(ha + 8 * j); X1[j] = ld4(ha + 32 * LDT + 8 * j);
-      }
-      if (!late) pair_post(pub + 2, it + 1, lane);         // (waits for the reads above)
-      // A wave that streams MFMAs keeps the SIMD's matrix pipe: its partner's MFMAs (and what follows them in
-      // program order) wait until the stream ends.  So the order of the two streams is chosen here, not left to
-      // the race: A's forward of the NEXT strip goes first (it needs nothing from this wave), and this wave's 128
-      // MFMAs follow it while A runs its loss, last layer and tile writes -- A's tiles are then ready when this
-      // stream ends.  The other order leaves the pipe idle while A finishes the strip this wave waits for.
-      if (hold) pair_wait(pub + 1, it + 2);
+      for (int j = 0; j < 4; ++j) { X0[j] = ld4(ha + 8 * j); X1[j] = ld4(ha + 32 * LDT + 8 * j); }
+      //   then g2, in the accumulator layout (the B operand of the input-gradient product) and as rows (the A
+      //   operand of dW1)
+      pair_wait(pub + 0, it + 1);
+      TRACE(1);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gB[kb][r] = sG2[(kb * 32 + feat(r, half)) * LDT + r32];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { G0[j] = ld4(ga + 8 * j); G1[j] = ld4(ga + 32 * LDT + 8 * j); }
+      pair_post(pub + 2, it + 1, lane);         // (waits for the reads above)
+      // Order of the two MFMA streams.  A wave that streams MFMAs keeps the SIMD's matrix pipe, and its partner's
+      // VALU work crawls meanwhile (26-28 cycles per instruction).  Left to the race, this wave's stream goes first
+      // and A's forward of the NEXT strip after it; A's loss and last layer then run with the pipe idle.  Held back
+      // until that forward has ended, this stream covers them instead, and A's forward covers this wave's mask.
+      if (hold) pair_wait(pub + 4, it + 2);
       TRACE(2);
       MATRIX_PHASE();
 #pragma unroll
@@ -1313,7 +1338,6 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
       TRACE(3);
       bwd_dx1(t, gB, sW1T, half, r32);
       VECTOR_PHASE();
-      if (late) pair_post(pub + 2, it + 1, lane);
       TRACE(4);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -1322,8 +1346,27 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
       put_tile(sG1, t, half, r32);
       wave_lds_fence();
       TRACE(5);
-      // layer 0: db0 and dW0 (VALU, fan-in <= 4)
-      vdb0 += row_sum32_dw4(sG1 + lane * LDT, sXp + (it % 3) * XT, dw0v);
+      // layer 0: dW0[n][k] += sum_row g1[n][row] x[k][row] as 32 one-step products of v_mfma_f32_4x4x1 (16 blocks of
+      // 4 features x 4 inputs: lane = feature on the A side, lane % 4 = input on the B side; 8 cycles each, against
+      // 128 FMAs on the VALU).  With a fan-in < 4 the x tile's row 3 is ones and column 3 is the bias gradient.
+      {
+        const float *grow = sG1 + lane * LDT, *xrow = sXp + (it % NXB) * XT + (lane & 3) * LDT;
+        float4 gv[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gv[i] = ld4(grow + 4 * i); xv[i] = ld4(xrow + 4 * i); }
+        MATRIX_PHASE();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dw0m = __builtin_amdgcn_mfma_f32_4x4x1f32(f4(gv[i], c), f4(xv[i], c), dw0m, 0, 0, 0);
+        VECTOR_PHASE();
+        if (K0 == 4) {
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { s0 += gv[i].x; s1 += gv[i].y; s2 += gv[i].z; s3 += gv[i].w; }
+          vdb0 += (s0 + s1) + (s2 + s3);
+        }
+      }
       pair_post(pub + 3, it + 1, lane);
       TRACE(6);
     }
@@ -1360,9 +1403,14 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
     for (int n = 0; n < NO; ++n) vsum[(pair * VS + 2 + n) * 64 + lane] = vec_wl[n];
     vsum[(pair * VS + 1) * 64 + lane] = vdb1;
   } else {
-    vsum[(pair * VS + 0) * 64 + lane] = vdb0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) vsum[(pair * VS + 2 + NO + k) * 64 + lane] = dw0v[k];
+    for (int i = 0; i < 4; ++i) vsum[(pair * VS + 2 + NO + (lane & 3)) * 64 + 4 * (lane >> 2) + i] = dw0m[i];
+    if (K0 == 4) {
+      vsum[(pair * VS + 0) * 64 + lane] = vdb0;
+    } else if ((lane & 3) == 3) {          // column 3 of the products: the ones row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vsum[(pair * VS + 0) * 64 + 4 * (lane >> 2) + i] = dw0m[i];
+    }
   }
   __syncthreads();
   for (int sl = tid >> 6; sl < 2 + NO + 4; sl += 8) {
