@@ -255,7 +255,7 @@ void run_one(float *out, unsigned long long *cyc, unsigned long long *h, int ite
   CK(hipMemcpy(h, cyc, 1024 * 8, hipMemcpyDeviceToHost));
   double s = 0;
   for (int i = 0; i < 1024; ++i) s += (double)h[i];
-  printf("one wave/SIMD: %2d v_fma + %d ds_read_b128 per MFMA: %7.1f cycles per MFMA\n", NV, NL, s / 1024 / iters / 4);
+  printf("one wave/SIMD: %2d v_fma + %d ds_read_b128 (each waited for) per MFMA: %7.1f cycles per MFMA\n", NV, NL, s / 1024 / iters / 4);
 }
 
 template <int NV>
@@ -268,7 +268,7 @@ void run_two(float *out, unsigned long long *cyc, unsigned long long *h, int ite
   double sm = 0, sv = 0;
   for (int b = 0; b < 256; ++b)
     for (int w = 0; w < 8; ++w) (w < 4 ? sm : sv) += (double)h[b * 8 + w];
-  printf("two waves/SIMD: MFMA wave %7.1f cycles per MFMA; partner with %2d v_fma per slot: %7.1f cycles per slot (%.1f per v_fma)\n",
+  printf("two waves/SIMD, equal rounds (the partner's average includes its solo tail after the MFMA wave has finished; see the chain rows): MFMA wave %7.1f cycles per MFMA; partner with %2d v_fma per slot: %7.1f cycles per slot (%.1f per v_fma)\n",
          sm / 1024 / iters / 4, NV, sv / 1024 / iters / 4, sv / 1024 / iters / 4 / NV);
 }
 
