@@ -623,7 +623,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
       'metric': 'learner transitions/sec (sample+loss+update)', 'value': round(value, 1), 'unit': 'transitions/s',
       'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-      'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix on the host (bit-exact)' if args.sampler == 'mt19937' else
+      'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix on the host (bit-exact; the next draw computed ahead on a helper thread, trl_randperm_prefix_ahead)' if args.sampler == 'mt19937' else
                  'philox on the device (throughput mode, not index-identical to torch.randperm)',
                  'parallelism': 'dp%d' % world, 'name': name,
                  'gemm_selection': 'blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)',

@@ -118,6 +118,17 @@ int trl_randperm_prefix(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, in
 int trl_randperm_prefix_direct(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, int64_t n, int64_t B,
                                int64_t *out_h);
 
+/* trl_randperm_prefix with the NEXT draw computed ahead of time, for the learner that samples every step from a
+ * full ring (`torch.randperm(len(buffer))[:batch_size]` once per step, examples/dqn.py:40, examples/ddpg.py:40).
+ * After returning this call's indices it starts, on a helper thread of the library, the draw of (next_n, B) from
+ * the state it leaves in mt / left / next (next_n <= 0: none).  The next call compares the state it is given with
+ * the one speculated from and, when they are equal (nobody else drew from the generator) and n == that next_n,
+ * copies the finished result instead of regenerating ~n / 624 MT19937 blocks on the caller's thread; anything
+ * else is computed as trl_randperm_prefix computes it.  Indices and final state are identical either way.
+ * *hit (may be NULL) is set to 1 when the speculated result was used.  One speculation per process. */
+int trl_randperm_prefix_ahead(uint32_t *mt /*[624]*/, int32_t *left, int32_t *next, int64_t n, int64_t B,
+                              int64_t *out_h, int64_t next_n, int32_t *hit);
+
 /* Throughput-mode sampler, on the device: B distinct indices uniform over [0, n) written to
  * idx_d (device int64 [B]), ready for trl_gather_rows -- the same distribution as
  * `torch.randperm(n)[:B]` (examples/dqn.py:40) but NOT the same indices (bit-exact indices are

@@ -74,6 +74,45 @@ def test_sampler_lockstep_with_torch(n, b):
   assert torch.equal(torch.randn(3), tail)
 
 
+def test_sampler_ahead_of_time_is_the_same_draw():
+  """trl_randperm_prefix_ahead: the next draw is computed on a helper thread from the state a call leaves; it is
+  used only when the generator is still in that state and n, B are the ones speculated -- and the indices and the
+  generator state are torch's own either way (hits, a draw in between, a changed n, a changed B)."""
+  from torchrl_amd.utils import sampler
+  n, b = 50021, 64
+  torch.manual_seed(99)
+  torch.rand(3)
+  exp = [torch.randperm(n)[:b] for _ in range(4)]
+  between = torch.rand(2)                        # someone else draws: the speculation is void
+  exp += [torch.randperm(n)[:b] for _ in range(2)]
+  exp.append(torch.randperm(n + 1)[:b])          # the ring grew
+  exp.append(torch.randperm(n + 1)[:b - 1])      # another batch size
+  tail = torch.randn(3)
+  torch.manual_seed(99)
+  torch.rand(3)
+  hits = []
+  for i in range(4):
+    assert torch.equal(sampler.randperm_prefix(n, b, next_n=n), exp[i])
+    hits.append(sampler.last_hit)
+  assert torch.equal(torch.rand(2), between)
+  for i in range(4, 6):
+    assert torch.equal(sampler.randperm_prefix(n, b, next_n=n), exp[i])
+    hits.append(sampler.last_hit)
+  assert torch.equal(sampler.randperm_prefix(n + 1, b, next_n=n + 1), exp[6])
+  hits.append(sampler.last_hit)
+  assert torch.equal(sampler.randperm_prefix(n + 1, b - 1, next_n=n + 1), exp[7])
+  hits.append(sampler.last_hit)
+  assert torch.equal(torch.randn(3), tail)
+  assert hits == [False, True, True, True, False, True, False, False], hits
+  # a plain call in between is a draw from the same generator: the pending speculation is simply not used
+  torch.manual_seed(5)
+  e2 = [torch.randperm(1000)[:10] for _ in range(3)]
+  torch.manual_seed(5)
+  assert torch.equal(sampler.randperm_prefix(1000, 10, next_n=1000), e2[0])
+  assert torch.equal(sampler.randperm_prefix(1000, 10), e2[1])
+  assert torch.equal(sampler.randperm_prefix(1000, 10, next_n=1000), e2[2]) and not sampler.last_hit
+
+
 def test_sampler_rejects_bad_arguments():
   from torchrl_amd.utils.sampler import randperm_prefix
   with pytest.raises(_lib.TrlError):

@@ -70,6 +70,8 @@ PROTOTYPES = {
     'trl_mt19937_seed': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.c_uint64]),
     'trl_randperm_prefix': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp]),
     'trl_randperm_prefix_direct': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp]),
+    'trl_randperm_prefix_ahead': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i64, _i64, _vp, _i64,
+                                             C.POINTER(_i32)]),
     'trl_sample_indices': (C.c_int, [_i64, _i64, C.c_uint64, _vp, _vp, _vp]),
     'trl_gae_reverse_scan': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _i32, _i32, _vp, _vp, _vp]),
     'trl_gae_reverse_scan_blocked': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _f64, _f64, _i32, _i32, _i64,

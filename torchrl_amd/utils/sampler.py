@@ -45,8 +45,15 @@ class Mt19937Sampler:
     return torch.from_numpy(out)
 
 
-def randperm_prefix(n, batch_size, generator=None):
-  """`torch.randperm(n, generator=generator)[:batch_size]`, bit for bit, in O(batch) memory."""
+last_hit = False     # whether the latest randperm_prefix(..., next_n=...) used the result computed ahead of time
+
+
+def randperm_prefix(n, batch_size, generator=None, next_n=None):
+  """`torch.randperm(n, generator=generator)[:batch_size]`, bit for bit, in O(batch) memory.
+
+  next_n: the `n` the caller expects to ask for next (a learner sampling a full ring every step: the same n).
+  The library then computes that draw on a helper thread from the state this call leaves, and the next call only
+  copies it if the generator is still in that state (trl_randperm_prefix_ahead); same indices, same state."""
   gen = torch.default_generator if generator is None else generator
   state = gen.get_state().numpy().copy()
   if state.size != _STATE_BYTES:
@@ -56,8 +63,15 @@ def randperm_prefix(n, batch_size, generator=None):
   left = C.c_int32(int(state[_OFF_LEFT:_OFF_LEFT + 4].view(np.int32)[0]))
   nxt = C.c_int32(int(state[_OFF_NEXT:_OFF_NEXT + 8].view(np.uint64)[0]))
   out = np.empty(int(batch_size), dtype=np.int64)
-  _lib.check(_lib.lib().trl_randperm_prefix(mt.ctypes.data, C.byref(left), C.byref(nxt), int(n),
-                                            int(batch_size), out.ctypes.data))
+  if next_n is None:
+    _lib.check(_lib.lib().trl_randperm_prefix(mt.ctypes.data, C.byref(left), C.byref(nxt), int(n),
+                                              int(batch_size), out.ctypes.data))
+  else:
+    global last_hit
+    hit = C.c_int32(0)
+    _lib.check(_lib.lib().trl_randperm_prefix_ahead(mt.ctypes.data, C.byref(left), C.byref(nxt), int(n),
+                                                    int(batch_size), out.ctypes.data, int(next_n), C.byref(hit)))
+    last_hit = bool(hit.value)
   mt64[:] = mt
   state[_OFF_LEFT:_OFF_LEFT + 4].view(np.int32)[0] = left.value
   state[_OFF_NEXT:_OFF_NEXT + 8].view(np.uint64)[0] = nxt.value

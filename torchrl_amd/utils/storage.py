@@ -439,7 +439,10 @@ class TensorTupleDataset(Dataset):
   def sample(self, batch_size, generator=None):
     """`self[torch.randperm(len(self), generator=generator)[:batch_size]]` (examples/dqn.py:40-41):
     identical indices, identical generator state afterwards."""
-    idx = randperm_prefix(self._count, batch_size, generator)
+    # a full ring is sampled with the same n every step: let the library draw the next prefix ahead of time
+    # (default generator only: the helper keeps one speculation per process)
+    ahead = self._count if (generator is None and self._count == self._capacity) else None
+    idx = randperm_prefix(self._count, batch_size, generator, next_n=ahead)
     return self._gather_host_index(idx)
 
   def sample_device(self, batch_size, seed=None):
