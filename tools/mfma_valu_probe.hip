@@ -113,6 +113,37 @@ __global__ __launch_bounds__(512) void k_chain(float *out, unsigned long long *c
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+// the same beside a stream of v_mfma_f32_16x16x4_f32 (8 passes, 32 cycles, the same FLOP rate): does the partner get
+// its VALU slots per MFMA or per cycle?
+template <int NC>
+__global__ __launch_bounds__(512) void k_chain16(float *out, unsigned long long *cyc, int iters, float seed) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const int wave = threadIdx.x >> 6;
+  f4v acc[4];
+  for (int j = 0; j < 4; ++j) acc[j] = f4v{0.f, 0.f, 0.f, 0.f};
+  float v[16];
+  for (int j = 0; j < 16; ++j) v[j] = seed + j;
+  float a = seed + threadIdx.x, b = seed * 2.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < 4) {
+    for (int it = 0; it < 48 * iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 256; ++k) v[k % NC] = __builtin_fmaf(v[k % NC], a, b);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  for (int j = 0; j < 16; ++j) s += v[j];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
 // 512 threads: waves 0-3 stream MFMAs; the partner runs NP (compare, select) pairs per slot -- v_cmp writes VCC, a
 // scalar register pair -- or, MODE 1, the same selection by integer arithmetic (no scalar register involved)
 template <int NP, int MODE>
@@ -286,6 +317,20 @@ void run_chain(float *out, unsigned long long *cyc, unsigned long long *h, int i
          NC, sv / 1024 / iters / 256);
 }
 
+template <int NC>
+void run_chain16(float *out, unsigned long long *cyc, unsigned long long *h, int iters) {
+  hipLaunchKernelGGL((k_chain16<NC>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  hipLaunchKernelGGL((k_chain16<NC>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h, cyc, 2048 * 8, hipMemcpyDeviceToHost));
+  double sv = 0, sm = 0;
+  for (int b = 0; b < 256; ++b)
+    for (int w = 0; w < 8; ++w) (w < 4 ? sm : sv) += (double)h[b * 8 + w];
+  printf("chain: beside a 16x16x4 MFMA stream (%5.1f cycles per MFMA): v_fma in %2d independent chains: %6.2f cycles per instruction\n",
+         sm / 1024 / (48.0 * iters) / 4, NC, sv / 1024 / iters / 256);
+}
+
 template <int NP, int MODE>
 void run_cmp(float *out, unsigned long long *cyc, unsigned long long *h, int iters) {
   hipLaunchKernelGGL((k_cmp<NP, MODE>), dim3(256), dim3(512), 0, 0, out, cyc, iters, 1e-9f);
@@ -358,6 +403,8 @@ int main() {
   run_chain<8, false>(out, cyc, h, 200);
   run_chain<16, true>(out, cyc, h, 200);
   run_chain<16, false>(out, cyc, h, 200);
+  run_chain16<1>(out, cyc, h, 200);
+  run_chain16<16>(out, cyc, h, 200);
   run_cmp<16, 0>(out, cyc, h, 1000);
   run_cmp<16, 2>(out, cyc, h, 1000);
   run_cmp<16, 1>(out, cyc, h, 1000);
