@@ -1,4 +1,5 @@
-"""A/B of the eight-wave and four-wave variants of k_ac_learn on one input (tuning build: TRL_LIB=tune)."""
+"""The role-split kernel k_ac_learn_pair against the four-wave k_ac_learn on one input (tuning build, TRL_LIB=tune:
+TRL_LEARN_NW=4 selects the four-wave kernel): losses and gradients, per parameter tensor."""
 import os
 os.environ['TRL_LIB'] = 'tune'
 import torch
@@ -13,13 +14,12 @@ obs = torch.randn(B, 3, generator=g).to(DEV); act = torch.randn(B, 1, generator=
 ret = torch.randn(B, 1, generator=g).to(DEV); adv = torch.randn(B, 1, generator=g).to(DEV)
 old = torch.zeros(B, 1, device=DEV)
 res = {}
-for nw in ('4', '8', '9'):
+for nw in ('4', '9'):
   os.environ['TRL_LEARN_NW'] = nw
   losses = ctl._fused(obs, act, ret, old, adv, 0.2, 0.5, 1e-3)
   torch.cuda.synchronize()
   res[nw] = (losses.clone().cpu(), ctl._flat.grad.clone().cpu())
 print('losses 4:', res['4'][0].tolist())
-print('losses 8:', res['8'][0].tolist())
 print('losses 9:', res['9'][0].tolist())
 print('pairs vs 4 waves: bitwise equal grads', bool(torch.equal(res['4'][1], res['9'][1])), 'losses', bool(torch.equal(res['4'][0], res['9'][0])))
 d = (res['4'][1] - res['9'][1]).abs()

@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   const int dynp = roleA ? (P.tune_prio & 3) : ((P.tune_prio >> 2) & 3);   // bits 1:0 / 3:2: priority of A's / B's matrix phases
 #define MATRIX_PHASE() do { if (dynp == 1) __builtin_amdgcn_s_setprio(1); else if (dynp == 2) __builtin_amdgcn_s_setprio(2); else if (dynp == 3) __builtin_amdgcn_s_setprio(3); } while (0)
 #define VECTOR_PHASE() do { if (dynp) __builtin_amdgcn_s_setprio(0); } while (0)
-  const bool hold = !(P.tune_prio & 32);                              // bit 5: no stream ordering
+  const bool hold = (P.tune_prio & 32) != 0;                          // bit 5: B's stream waits for A's next forward
 #else
   const bool roleA = wave < 4;
   constexpr bool hold = false;
