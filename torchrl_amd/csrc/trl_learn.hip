@@ -188,31 +188,6 @@ __device__ __forceinline__ float row_sum32(const float *row) {
   return (s0 + s1) + (s2 + s3);
 }
 
-// Layer-0 weight gradient on the VALU for observations of at most 4 features (Pendulum 3, CartPole 4):
-// lane = feature n reads its own gradient row g[n][0..31] (which the bias gradient needs anyway) and
-// the 4 rows of x^T as broadcast 16 B reads, and adds  dw[k] += sum_row g[n][row] x[k][row].  On the
-// MFMA this product is 32 instructions per strip (2,048 cycles of the matrix pipe) for a 64 x 3 result
-// padded to 64 x 32; here it is 128 FMAs.  Returns the row sum (same order as row_sum32).
-__device__ __forceinline__ float row_sum32_dw4(const float *grow, const float *sX, float (&dw)[4]) {
-  float4 v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = ld4(grow + 4 * i);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4 x = ld4(sX + k * LDT + 4 * i);
-      a0 = fmaf(v[i].x, x.x, a0); a1 = fmaf(v[i].y, x.y, a1); a2 = fmaf(v[i].z, x.z, a2); a3 = fmaf(v[i].w, x.w, a3);
-    }
-    dw[k] += (a0 + a1) + (a2 + a3);
-  }
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { s0 += v[i].x; s1 += v[i].y; s2 += v[i].z; s3 += v[i].w; }
-  return (s0 + s1) + (s2 + s3);
-}
-
 // Last-layer weight gradient per FEATURE instead of per lane-partial (wide two-output variant): lane = feature f
 // reads its own activation row h[f][0..31] of the strip and, as broadcast 16 B reads, the NO rows of the output
 // gradient gout[n][0..31], and adds  dwl[n] += sum_row gout[n][row] h[f][row].  One accumulator register per
@@ -563,17 +538,21 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int qb0 = RC ? (int)blockIdx.z * NBQ : 0;
   float dwlv[NBQ][NO];          // WLV: last-layer weight gradient of feature `lane` of block q
   float vdb0[NBQ], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
-  // fan-in <= 4: dW0[lane][k] accumulates per lane on the VALU (row_sum32_dw4) instead of in accW0
+  // fan-in <= 4: dW0 of a block is 32 one-step products of v_mfma_f32_4x4x1 per strip (16 blocks of 4 features x 4
+  // inputs: lane = feature on the A side, lane % 4 = input on the B side; 8 cycles each) instead of 32 padded
+  // 32x32x2 MFMAs into accW0; element i of dw0m is dW0[4 (lane / 4) + i][lane % 4].  With a fan-in < 4 row 3 of the
+  // x tile holds ones (W0's column 3 is zero, so the forward does not see them) and column 3 is the bias gradient.
   const bool w0v = HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
-  float dw0v[NBQ][4];
+  const bool ones3 = w0v && K0 < 4;
+  if (ones3 && lane < 32) sX[3 * LDT + lane] = 1.f;
+  f32x4 dw0m[NBQ];
   f32x16 dWL[WLV ? 1 : NBQ][NO][2];
 #pragma unroll
   for (int qb = 0; qb < NBQ; ++qb) {
 #pragma unroll
     for (int n = 0; n < NO; ++n) dwlv[qb][n] = 0.f;
     vdb0[qb] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dw0v[qb][k] = 0.f;
+    dw0m[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float dbL[NO];
 #pragma unroll
@@ -823,7 +802,21 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     wave_lds_fence();
     PH(9);
     if (w0v) {
-      vdb0[qb] += row_sum32_dw4(sG + lane * LDT, sX, dw0v[qb]);
+      const float *grow = sG + lane * LDT, *xrow = sX + (lane & 3) * LDT;
+      float4 gv[8], xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { gv[i] = ld4(grow + 4 * i); xv[i] = ld4(xrow + 4 * i); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          dw0m[qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4(gv[i], c), f4(xv[i], c), dw0m[qb], 0, 0, 0);
+      if (!ones3) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0 += gv[i].x; s1 += gv[i].y; s2 += gv[i].z; s3 += gv[i].w; }
+        vdb0[qb] += (s0 + s1) + (s2 + s3);
+      }
     } else {
       const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
       float4 g0 = ld4(ga), g1 = ld4(ga + 32 * LDT), xv[KB0];
@@ -942,12 +935,17 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
   for (int qb = 0; qb < NBQ; ++qb) {         // one round per 64-wide block of the hidden layer
     if (qb) __syncthreads();                 // the previous round's sums are out
-    vsum[(wave * VS + 0) * 64 + lane] = vdb0[qb];
+    if (!ones3) {
+      vsum[(wave * VS + 0) * 64 + lane] = vdb0[qb];
+    } else if ((lane & 3) == 3) {              // column 3 of the 4x4 products: the ones row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vsum[(wave * VS + 0) * 64 + 4 * (lane >> 2) + i] = dw0m[qb][i];
+    }
     vsum[(wave * VS + 1) * 64 + lane] = vec_db1;
 #pragma unroll
     for (int n = 0; n < NO; ++n) vsum[(wave * VS + 2 + n) * 64 + lane] = vec_wl[qb][n];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) vsum[(wave * VS + 2 + NO + k) * 64 + lane] = dw0v[qb][k];
+    for (int i = 0; i < 4; ++i) vsum[(wave * VS + 2 + NO + (lane & 3)) * 64 + 4 * (lane >> 2) + i] = dw0m[qb][i];
     __syncthreads();
     for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += NW) {
       const int f = tid & 63, fq = (qb0 + qb) * 64 + f;
