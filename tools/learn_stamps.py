@@ -13,10 +13,12 @@ from torchrl_amd import functional as F  # noqa: E402
 from torchrl_amd.contrib.controllers import PPOController  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-NW = int(os.environ.get('TRL_LEARN_NW', '8')) if B >= 32768 else 4     # waves per workgroup of the variant taken
+NW = 4     # waves per workgroup (k_ac_learn; run with TRL_LEARN_NW=4: the pair kernel has its own trace tool)
+os.environ.setdefault('TRL_LEARN_NW', '4')
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
-ctl = PPOController(3, 1, device=dev, hidden=(64, 64))
+HIDDEN = tuple(int(x) for x in os.environ.get('HIDDEN', '64,64').split(','))
+ctl = PPOController(3, 1, device=dev, hidden=HIDDEN if len(HIDDEN) > 1 else HIDDEN[0])
 obs, act = torch.randn(B, 3, device=dev), torch.randn(B, 1, device=dev)
 ret, adv, old = torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev) - 1
 f = ctl._fused
@@ -24,7 +26,8 @@ for _ in range(int(os.environ.get('ITERS', 3000))):          # >= 2 s of back-to
   f(obs, act, ret, old, adv, 0.2, 0.5, 1e-3)
 torch.cuda.synchronize()
 ws = f._ws.buf.view(torch.uint8)
-np_c, np_a = 4481, 4481
+np_c = sum(p.numel() for p in ctl.ac_net.critic.parameters())
+np_a = sum(p.numel() for p in ctl.ac_net.actor.parameters())
 pstride = (max(np_c, np_a) + 8 + 3) // 4 * 4
 nwg = min(128, (B + 32 * NW - 1) // (32 * NW))
 raw = ws[2 * 128 * pstride * 4:2 * 128 * pstride * 4 + 2 * nwg * NW * 64].cpu().numpy().view(np.uint64)
