@@ -54,5 +54,8 @@ nst = (B + 31) // 32 / (nwg * NW)
 names = {5: 'loop top -> inputs in registers', 6: 'x tile write + fence', 7: 'layer 0 forward + relu', 8: 'layer 1 forward + relu',
          0: 'last layer forward', 1: 'loss + last layer backward', 2: 'layer 1 backward (tiles, dW1, g0, mask)',
          9: 'layer 0 backward: db0, tile, fence', 3: 'layer 0 backward: dW0 MFMAs'}
+if len(HIDDEN) == 1 and HIDDEN[0] > 64:       # k_ac_learn_wide
+  names = {5: 'loop top -> inputs in registers', 6: 'x tile write, fence, operand read', 7: 'forward: layer 0, relu, last layer dots',
+           0: 'last layer finish', 1: 'loss, gout rows write, fence, reads', 3: 'backward (lane = feature)', 8: '-', 2: '-', 9: '-'}
 for k in (5, 6, 7, 8, 0, 1, 2, 9, 3):
   print('  phase %-42s %8.0f cycles per strip' % (names[k], np.median(ph[:, k]) / nst))

@@ -1,4 +1,5 @@
-"""Device time of one fused PPO learn() launch pair at a batch (tuning build; env knobs TRL_LEARN_NW / TRL_LEARN_PRIO)."""
+"""Device time of one fused PPO learn() launch pair at a batch (tuning build; env knobs
+HIDDEN / OBS / ACT, TRL_LEARN_NW / TRL_LEARN_PRIO; argv: batch, then K=V,K=V labels / env settings per timed run)."""
 import os
 import sys
 
@@ -13,7 +14,8 @@ A = int(os.environ.get('ACT', 1))
 OBS = int(os.environ.get('OBS', 3))
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
-ctl = PPOController(OBS, A, device=dev, hidden=(64, 64))
+HIDDEN = tuple(int(x) for x in os.environ.get('HIDDEN', '64,64').split(','))
+ctl = PPOController(OBS, A, device=dev, hidden=HIDDEN if len(HIDDEN) > 1 else HIDDEN[0])
 obs, act = torch.randn(B, OBS, device=dev), torch.randn(B, A, device=dev)
 ret, adv, old = torch.randn(B, 1, device=dev), torch.randn(B, 1, device=dev), torch.randn(B, A, device=dev) - 1
 f = ctl._fused

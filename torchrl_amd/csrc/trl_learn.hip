@@ -40,6 +40,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int LDT = 36;       // row stride of the [feature][row] transpose tiles (16 B rows: ds_read_b128 operands)
 constexpr int LDW = 68;       // row stride of the 64 x 64 weight tiles
@@ -268,6 +269,23 @@ __device__ __forceinline__ void fwd_last_acc(float (&p)[NO], const f32x16 (&hl)[
         p[n] = fmaf(w4.y, hl[kb][4 * q + 1], p[n]);
         p[n] = fmaf(w4.z, hl[kb][4 * q + 2], p[n]);
         p[n] = fmaf(w4.w, hl[kb][4 * q + 3], p[n]);
+      }
+  }
+}
+
+// the same dot products two features at a time (v_pk_fma_f32: a register pair of the activations times a pair of the
+// 16 B weight read); p[n] = (sum over even registers, sum over odd registers)
+template <int NO>
+__device__ __forceinline__ void fwd_last_acc2(f32x2 (&p)[NO], const f32x16 (&hl)[2], const float *sWL, int half) {
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
+        p[n] = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, f32x2{hl[kb][4 * q + 0], hl[kb][4 * q + 1]}, p[n]);
+        p[n] = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, f32x2{hl[kb][4 * q + 2], hl[kb][4 * q + 3]}, p[n]);
       }
   }
 }
@@ -974,6 +992,336 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     } else {                                  // dbL[n]
       const int n = tid - 2 - NO;
       if (n < NOr) part[a.poff[D - 1] + NOr * HL + n] = v;
+    }
+  }
+  STAMP(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One WIDE hidden layer (65 .. 256 units: the reference's own ActorCriticNet / A2CNet width, ppo_controller.py:14)
+// over a fan-in of at most 4.  That shape has no square product: per 64-feature block only layer 0 (K <= 4), the
+// last layer's dot product and their transposes, so the step is VALU- and LDS-bound, not MFMA-bound, and what counts
+// is instructions per strip.  k_ac_learn's plan (activations held from forward to backward, every gradient tile
+// transposed through LDS) needs 128 + 128 registers for 4 blocks and ran out of them.  Here nothing is held and
+// nothing is transposed: layer 0 is computed TWICE, in the two accumulator layouts the MFMA offers for free --
+//   forward:  H^T = W0' X'^T  (A = weights, B = samples): lane = sample, register = feature.  The last layer's dot
+//             product is then a per-lane FMA chain, as in k_ac_learn; the activations are dropped.
+//   backward: H   = X' W0'^T  (the SAME two operand registers, swapped): lane = feature, register = sample.  The
+//             ReLU mask, g = (WL^T gout) * mask, dWL[f] += sum_row h g_out, and the 4x4x1 MFMA outer products
+//             dW0[f][k] += g[f][row] x[k][row] all reduce over REGISTERS of the lane that owns feature f: one
+//             accumulator per feature, no LDS tile.  The recompute is 2-3 MFMAs per 32 features.
+// W0' = [W0 | b0] and X' = [x | 1] (the bias is one more k column, so the products start from C = 0, and for a fan-in
+// < 4 column K0 of the dW0 products is the bias gradient; a fan-in of 4 sums it beside them).  W0's operands and the
+// lane's own last-layer weights are loop-invariant and live in registers; per strip the wave reads only the x tile,
+// the last layer's rows (forward) and the strip's output gradients from LDS.  One output (NO == 1): WL[f] is a
+// factor of the whole of feature f's layer-0 gradient and is applied once, at the end.
+// (amdgpu_waves_per_eu(2): with a budget of 256 registers the compiler takes the MFMA results in VGPRs; with the 512
+// of one wave per SIMD it puts them in AGPRs and pays a v_accvgpr_read per element ahead of every VALU use)
+template <int NO, int HB, bool K4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ac_learn_wide(LearnArgs P) {
+  constexpr int NW = 4, NT = 64 * NW, F = HB * 64;
+  constexpr int XR = 6;                               // rows of the x tile: <= 4 inputs, the ones row, zeros to an even count
+  constexpr int XT = XR * LDT + 4;                    // (+ a dummy slot for idle prefetch lanes)
+  constexpr int WT = XT + NO * LDT;                   // per-wave scratch: x^T tile, output-gradient rows
+  constexpr int NS = NO + 5;                          // per-feature sums: NO rows of dWL, 4 columns of dW0, db0 (fan-in 4)
+  constexpr int OFF_WL = 0, OFF_BL = OFF_WL + HB * NO * 64, OFF_S = OFF_BL + 4, OFF_T = OFF_S + NW * 16,
+                OFF_R = OFF_T + NW * WT;
+  static_assert(XT % 4 == 0 && WT % 4 == 0 && OFF_T % 4 == 0, "16 B rows");
+  __shared__ __align__(16) float smem[OFF_R + 2 * NW * NS * F];
+  float *const sWL = smem + OFF_WL, *const sBL = smem + OFF_BL, *const scal = smem + OFF_S, *const sR = smem + OFF_R;
+
+  const int net = blockIdx.y;
+  const NetArgs &a = P.net[net];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5,
+            r32 = lane & 31;
+  const int K0 = a.dims[0], H1 = a.dims[1], NOr = a.dims[2];
+  const int64_t B = P.B;
+  const int A = P.A;
+
+  STAMP(0);
+  for (int e = tid; e < HB * NO * 64; e += NT) {      // block q of the hidden features at sWL + q * NO * 64, [n][64]
+    const int q = e / (NO * 64), r = e - q * NO * 64, n = r >> 6, k = q * 64 + (r & 63);
+    sWL[e] = (n < NOr && k < H1) ? a.w[1][n * H1 + k] : 0.f;
+  }
+  if (tid < 4) sBL[tid] = tid < NOr ? a.b[1][tid] : 0.f;
+  float *sX = smem + OFF_T + wave * WT;     // [XR][LDT]  x'^T of the strip: rows < K0 the observation, row K0 ones
+  float *sGo = sX + XT;                     // [NO][LDT]  gradient w.r.t. the outputs
+  for (int e = lane; e < WT; e += 64) sX[e] = 0.f;
+  if (lane < 32) sX[K0 * LDT + lane] = 1.f;
+  // layer 0's weight operand, the same register for both products: W0'[f][k = 2 s + half] of feature
+  // f = 64 q + 32 nb + (lane & 31); and the lane's own last-layer weights
+  constexpr int KS = K4 ? 3 : 2;            // k steps of two: the inputs and the bias column (a compile-time count:
+                                            // a branch around an MFMA costs copies of its 16 accumulators)
+  float wop[HB][2][KS];
+#pragma unroll
+  for (int q = 0; q < HB; ++q)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int f = q * 64 + nb * 32 + r32;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + half;
+        float v = 0.f;
+        if (f < H1 && k < K0) v = a.w[0][f * K0 + k];
+        if (f < H1 && k == K0) v = a.b[0][f];
+        wop[q][nb][s] = v;
+      }
+    }
+  __syncthreads();
+  STAMP(1);
+
+  // ---- per-wave persistent state: everything per FEATURE (lane & 31 of block q, half nb), summed over the rows
+  // 8 j + 4 half + i of every strip
+  f32x2 dwl[HB][2][NO], vdb0[HB][2];     // (even rows, odd rows)
+  f32x4 dw0m[HB][2];       // element i of lane 4 b + k: dW0[feature 4 (b & 7) + i][k], rows of half b >> 3
+#pragma unroll
+  for (int q = 0; q < HB; ++q)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int n = 0; n < NO; ++n) dwl[q][nb][n] = f32x2{0.f, 0.f};
+      vdb0[q][nb] = f32x2{0.f, 0.f};
+      dw0m[q][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  // K4: a fan-in of 4 leaves no room for the ones row among the four B lanes, and db0 is summed on the VALU
+  float dbL[NO], s_main = 0.f, s_ent = 0.f, s_dls[NO], den[NO], var[NO], logsig[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    dbL[n] = 0.f; s_dls[n] = 0.f;
+    den[n] = var[n] = 1.f; logsig[n] = 0.f;
+    if (net == 1 && P.kind == KIND_PPO && n < A) {
+      const float sigma = expf(P.log_std[n]);   // self.log_std.exp()
+      var[n] = uni(sigma * sigma);              // scale ** 2
+      logsig[n] = uni(logf(sigma));             // scale.log()
+      den[n] = uni(2.0f * (sigma * sigma));
+    }
+  }
+  const float invB = uni(1.0f / (float)B);
+  const float gmin = uni(-(1.0f / (float)(B * A)));   // d loss / d min(surr1, surr2) element
+
+  // ---- a strip's inputs are fetched one strip ahead, into registers, branch-free (as in k_ac_learn)
+  constexpr int XPF = 2;
+  const int nelem = 32 * K0;
+  int xoff[XPF];
+#pragma unroll
+  for (int j = 0; j < XPF; ++j) {
+    const int e = lane + 64 * j;
+    xoff[j] = e < nelem ? (e % K0) * LDT + e / K0 : XT - 4;
+  }
+  const float *in0 = net == 0 ? P.returns : P.adv;
+  const float *in_act[NO], *in_olp[NO];
+  const bool ppo_actor = net == 1 && P.kind == KIND_PPO;
+  const int astr = ppo_actor ? A : 1;
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {      // A2C: the action index of the row, in every slot
+    in_act[n] = net == 0 ? in0 : (ppo_actor ? P.action + (n < A ? n : 0) : P.action);
+    in_olp[n] = ppo_actor ? P.old_logp + (n < A ? n : 0) : in0;
+  }
+  float xr[XPF], p_in0 = 0.f, p_act[NO], p_olp[NO];
+  const int64_t nstrips = (B + 31) >> 5;
+  auto fetch = [&](int64_t strip) {      // (strip is wave-uniform: scalar bases, 32-bit lane offsets)
+    strip = strip < nstrips ? strip : nstrips - 1;
+    const int64_t row0 = strip << 5;
+    const int64_t left = B - row0;
+    const int rows = (int)(left < 32 ? left : 32);
+    const int rl = r32 < rows ? r32 : rows - 1;
+    const float *base = P.obs + row0 * K0;
+    const int last = rows * K0 - 1;
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) {
+      const int e = lane + 64 * j;
+      xr[j] = base[e < last ? e : last];
+    }
+    p_in0 = (in0 + row0)[rl];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      p_act[n] = (in_act[n] + row0 * astr)[rl * astr];
+      p_olp[n] = (in_olp[n] + row0 * astr)[rl * astr];
+    }
+  };
+
+  const int64_t sstride = (int64_t)gridDim.x * NW;
+  int64_t strip = (int64_t)blockIdx.x * NW + wave;
+  fetch(strip);
+  PH_DECL
+  for (; strip < nstrips; strip += sstride) {
+    const bool valid = (strip << 5) + r32 < B;
+    PH(5);
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
+    const float ret = p_in0, ad = p_in0;
+    float act[NO], olp[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
+    fetch(strip + sstride);
+    wave_lds_fence();
+    float xop[KS];           // the sample operand, the same register for both products: x'[row = lane & 31][k = 2 s + half]
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xop[s] = sX[(2 * s + half) * LDT + r32];
+    PH(6);
+
+    // ---- forward (lane = sample): out = WL relu(W0' x') + bL, block by block; the activations are not kept
+    float out[NO];
+    // (an offset the compiler cannot see through: it may otherwise prove the last layer's rows loop-invariant and
+    // hold all of them in registers across the strip loop)
+    int wl_off = 0;
+    asm volatile("" : "+v"(wl_off));
+    {
+      f32x2 pacc2[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) pacc2[n] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < HB; ++q) {
+        f32x16 h[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[nb][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          h[0] = MFMA(wop[q][0][s], xop[s], h[0]);
+          h[1] = MFMA(wop[q][1][s], xop[s], h[1]);
+        }
+        relu2(h);
+        fwd_last_acc2<NO>(pacc2, h, sWL + wl_off + q * NO * 64, half);
+        // (one block at a time: left alone, the scheduler interleaves all blocks' products and parks their
+        // accumulators in AGPRs, a copy in and a copy out per use)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      PH(7);
+      float pacc[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) pacc[n] = pacc2[n].x + pacc2[n].y;
+      fwd_last_finish<NO>(out, pacc, sBL);
+    }
+    PH(0);
+    // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
+    float gout[NO];
+    loss_grad<NO>(P, net, A, valid, half, LossConst{invB, gmin}, out, ret, ad, act, olp, den, var, logsig, gout, s_main,
+                  s_ent, s_dls);
+#pragma unroll
+    for (int n = 0; n < NO; ++n)
+      if (half == 0) dbL[n] += gout[n];
+    if (half == 0) {
+#pragma unroll
+      for (int n = 0; n < NO; ++n) sGo[n * LDT + r32] = gout[n];
+    }
+    wave_lds_fence();
+    // rows 8 j + 4 half + i of the strip, register 4 j + i: the output gradients (broadcast reads) and, for the
+    // 4x4 products, input (lane & 3) of those rows
+    float4 go[NO][4], xq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int n = 0; n < NO; ++n) go[n][j] = ld4(sGo + n * LDT + 8 * j + 4 * half);
+      xq[j] = ld4(sX + (lane & 3) * LDT + 8 * j + 4 * half);
+    }
+    PH(1);
+
+    // ---- backward (lane = feature)
+#pragma unroll
+    for (int q = 0; q < HB; ++q)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        f32x16 pre;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pre[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pre = MFMA(xop[s], wop[q][nb][s], pre);
+        float wlb[NO];       // the feature's own last-layer weights (read under the MFMAs)
+#pragma unroll
+        for (int n = 0; n < NO; ++n) wlb[n] = NO == 1 ? 0.f : sWL[wl_off + (q * NO + n) * 64 + nb * 32 + r32];
+        // two rows at a time: the pair (r, r + 1) is a register pair of the product and of the 16 B reads, so the
+        // FMAs are v_pk_fma_f32 (two per instruction, no moves); sums of even and odd rows are kept apart
+        f32x2 sdb = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 x = {pre[r], pre[r + 1]};
+          f32x2 gn[NO], av;
+#pragma unroll
+          for (int n = 0; n < NO; ++n) {
+            const float4 g4 = go[n][r >> 2];
+            gn[n] = (r & 2) ? f32x2{g4.z, g4.w} : f32x2{g4.x, g4.y};
+          }
+          if constexpr (NO == 1) {
+            av = f32x2{x.x > 0.f ? gn[0].x : 0.f, x.y > 0.f ? gn[0].y : 0.f};      // (WL[f] is applied at the end)
+            dwl[q][nb][0] = __builtin_elementwise_fma(x, av, dwl[q][nb][0]);    // x > 0 wherever av != 0
+          } else {
+            const f32x2 hr = {__int_as_float(__float_as_int(x.x) > 0 ? __float_as_int(x.x) : 0),
+                              __int_as_float(__float_as_int(x.y) > 0 ? __float_as_int(x.y) : 0)};
+            f32x2 t = f32x2{wlb[0], wlb[0]} * gn[0];
+#pragma unroll
+            for (int n = 1; n < NO; ++n) t = __builtin_elementwise_fma(f32x2{wlb[n], wlb[n]}, gn[n], t);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) dwl[q][nb][n] = __builtin_elementwise_fma(hr, gn[n], dwl[q][nb][n]);
+            av = f32x2{x.x > 0.f ? t.x : 0.f, x.y > 0.f ? t.y : 0.f};
+          }
+          const float4 x4 = xq[r >> 2];
+          dw0m[q][nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, (r & 2) ? x4.z : x4.x, dw0m[q][nb], 0, 0, 0);
+          dw0m[q][nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, (r & 2) ? x4.w : x4.y, dw0m[q][nb], 0, 0, 0);
+          if (K4) sdb += av;
+        }
+        if (K4) vdb0[q][nb] += sdb;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    wave_lds_fence();     // the next strip overwrites sX and sGo
+    PH(3);
+  }
+  PH_OUT;
+
+  STAMP(2);
+  // =========================================================================== partials out
+  float *part = P.ws + ((int64_t)net * gridDim.x + blockIdx.x) * P.pstride;
+  float sc[2 + 2 * NO];
+  sc[0] = trl_wave_sum(s_main);
+  sc[1] = trl_wave_sum(s_ent);
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    sc[2 + n] = trl_wave_sum(s_dls[n]);
+    sc[2 + NO + n] = trl_wave_sum(dbL[n]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
+  }
+  // per-feature sums: one copy per (wave, lane half), added in that order
+  float *mine = sR + (wave * 2 + half) * NS * F;
+#pragma unroll
+  for (int q = 0; q < HB; ++q)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int fb = q * 64 + nb * 32;
+#pragma unroll
+      for (int n = 0; n < NO; ++n) mine[n * F + fb + r32] = dwl[q][nb][n].x + dwl[q][nb][n].y;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mine[(NO + (lane & 3)) * F + fb + 4 * (r32 >> 2) + i] = dw0m[q][nb][i];
+      mine[(NO + 4) * F + fb + r32] = vdb0[q][nb].x + vdb0[q][nb].y;
+    }
+  __syncthreads();
+  for (int e = tid; e < NS * F; e += NT) {
+    const int sl = e / F, f = e - sl * F;
+    float v = sR[e];
+#pragma unroll
+    for (int c = 1; c < 2 * NW; ++c) v += sR[c * NS * F + e];
+    if (f >= H1) continue;
+    if (sl < NO) {
+      if (sl < NOr) part[a.poff[1] + sl * H1 + f] = v;
+    } else {
+      const int k = sl - NO;
+      if (NO == 1) v *= sWL[(f >> 6) * 64 + (f & 63)];
+      if (k < K0) part[a.poff[0] + f * K0 + k] = v;
+      else if (k == K0) part[a.poff[0] + H1 * K0 + f] = v;      // the ones column, or (fan-in 4) the VALU sum
+    }
+  }
+  if (tid < 2 + 2 * NO) {
+    float v = scal[tid];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += scal[w * 16 + tid];
+    if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
+      if (tid < 2 + A) part[a.nparams + tid] = v;
+    } else {                                  // dbL[n]
+      const int n = tid - 2 - NO;
+      if (n < NOr) part[a.poff[1] + NOr * H1 + n] = v;
     }
   }
   STAMP(3);
@@ -1810,12 +2158,14 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
     if (NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair<1>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_ac_learn_pair<2>), grid, block, 0, st, P);
   } else if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
-    // (4 blocks x 2 outputs: the last layer's weight gradient is accumulated per feature from LDS tiles, WLV)
     TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
-    if (hmax <= 128 && NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 2>), grid, block, 0, st, P);
-    else if (hmax <= 128) hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 2>), grid, block, 0, st, P);
-    else if (NOv == 1) hipLaunchKernelGGL((k_ac_learn<2, 1, 1, true, 4>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((k_ac_learn<2, 1, 2, true, 4>), grid, block, 0, st, P);   // WLV: per-feature dWL
+#define TRL_WIDE_CASE(no, hb)                                                                     \
+  if (NOv == no && (hmax <= 128 ? 2 : 4) == hb) {                                                  \
+    if (critic->dims[0] == 4) hipLaunchKernelGGL((k_ac_learn_wide<no, hb, true>), grid, block, 0, st, P); \
+    else hipLaunchKernelGGL((k_ac_learn_wide<no, hb, false>), grid, block, 0, st, P);             \
+  }
+    TRL_WIDE_CASE(1, 2) TRL_WIDE_CASE(2, 2) TRL_WIDE_CASE(1, 4) TRL_WIDE_CASE(2, 4)
+#undef TRL_WIDE_CASE
   } else {
   TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
   TRL_LEARN_CASE(2, 2, 1) TRL_LEARN_CASE(2, 2, 2) TRL_LEARN_CASE(2, 2, 4)
