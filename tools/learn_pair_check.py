@@ -1,8 +1,10 @@
 """The role-split kernel k_ac_learn_pair against the four-wave k_ac_learn on one input (tuning build, TRL_LIB=tune:
 TRL_LEARN_NW=4 selects the four-wave kernel): losses and gradients, per parameter tensor."""
 import os
+import sys
 os.environ['TRL_LIB'] = 'tune'
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torchrl_amd.contrib.controllers import PPOController
 
 DEV = 'cuda:0'

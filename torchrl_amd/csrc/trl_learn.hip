@@ -189,27 +189,6 @@ __device__ __forceinline__ float row_sum32(const float *row) {
   return (s0 + s1) + (s2 + s3);
 }
 
-// Last-layer weight gradient per FEATURE instead of per lane-partial (wide two-output variant): lane = feature f
-// reads its own activation row h[f][0..31] of the strip and, as broadcast 16 B reads, the NO rows of the output
-// gradient gout[n][0..31], and adds  dwl[n] += sum_row gout[n][row] h[f][row].  One accumulator register per
-// (block, output) instead of 32: 4 blocks x 2 outputs no longer need 256 registers, nor a split launch.
-template <int NO>
-__device__ __forceinline__ void rows_dwl(const float *hrow, const float *sGo, float (&dwl)[NO]) {
-  float4 v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = ld4(hrow + 4 * i);
-#pragma unroll
-  for (int n = 0; n < NO; ++n) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4 x = ld4(sGo + n * LDT + 4 * i);
-      a0 = fmaf(v[i].x, x.x, a0); a1 = fmaf(v[i].y, x.y, a1); a2 = fmaf(v[i].z, x.z, a2); a3 = fmaf(v[i].w, x.w, a3);
-    }
-    dwl[n] += (a0 + a1) + (a2 + a3);
-  }
-}
-
 // ---- forward pieces, shared by the learner kernel and the inference kernel
 // layer 0: h1^T = relu(W0 x^T + b0); x^T from the strip's LDS tile, k walked in natural order
 template <int LDW0>
@@ -255,28 +234,11 @@ __device__ __forceinline__ void fwd_layer1(f32x16 (&h2)[2], const f32x16 (&h1)[2
   relu2(h2);
 }
 
-// last layer on the VALU: out[n] = WL[n] . hl + bL[n] (both lane halves end with the row's value)
+// last layer on the VALU: out[n] = WL[n] . hl + bL[n] (both lane halves end with the row's value).  Two features
+// at a time (v_pk_fma_f32: a register pair of the activations times a pair of the 16 B weight read);
+// p[n] = (sum over even registers, sum over odd registers)
 template <int NO>
-__device__ __forceinline__ void fwd_last_acc(float (&p)[NO], const f32x16 (&hl)[2], const float *sWL, int half) {
-#pragma unroll
-  for (int n = 0; n < NO; ++n) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
-        p[n] = fmaf(w4.x, hl[kb][4 * q + 0], p[n]);
-        p[n] = fmaf(w4.y, hl[kb][4 * q + 1], p[n]);
-        p[n] = fmaf(w4.z, hl[kb][4 * q + 2], p[n]);
-        p[n] = fmaf(w4.w, hl[kb][4 * q + 3], p[n]);
-      }
-  }
-}
-
-// the same dot products two features at a time (v_pk_fma_f32: a register pair of the activations times a pair of the
-// 16 B weight read); p[n] = (sum over even registers, sum over odd registers)
-template <int NO>
-__device__ __forceinline__ void fwd_last_acc2(f32x2 (&p)[NO], const f32x16 (&hl)[2], const float *sWL, int half) {
+__device__ __forceinline__ void fwd_last_acc(f32x2 (&p)[NO], const f32x16 (&hl)[2], const float *sWL, int half) {
 #pragma unroll
   for (int n = 0; n < NO; ++n) {
 #pragma unroll
@@ -291,10 +253,11 @@ __device__ __forceinline__ void fwd_last_acc2(f32x2 (&p)[NO], const f32x16 (&hl)
 }
 
 template <int NO>
-__device__ __forceinline__ void fwd_last_finish(float (&out)[NO], const float (&p)[NO], const float *sBL) {
+__device__ __forceinline__ void fwd_last_finish(float (&out)[NO], const f32x2 (&p)[NO], const float *sBL) {
 #pragma unroll
   for (int n = 0; n < NO; ++n) {
-    const float t = p[n] + __shfl_xor(p[n], 32, 64);
+    const float s = p[n].x + p[n].y;
+    const float t = s + __shfl_xor(s, 32, 64);
     out[n] = t + sBL[n];
   }
 }
@@ -302,9 +265,9 @@ __device__ __forceinline__ void fwd_last_finish(float (&out)[NO], const float (&
 template <int NO>
 __device__ __forceinline__ void fwd_last(float (&out)[NO], const f32x16 (&hl)[2], const float *sWL,
                                          const float *sBL, int half) {
-  float p[NO];
+  f32x2 p[NO];
 #pragma unroll
-  for (int n = 0; n < NO; ++n) p[n] = 0.f;
+  for (int n = 0; n < NO; ++n) p[n] = f32x2{0.f, 0.f};
   fwd_last_acc<NO>(p, hl, sWL, half);
   fwd_last_finish<NO>(out, p, sBL);
 }
@@ -488,30 +451,21 @@ __device__ __forceinline__ void loss_grad(const LearnArgs &P, int net, int A, bo
 // D = depth (2: in -> H -> out, 3: in -> H -> H -> out); KB0 = 32-blocks of the fan-in;
 // NO = padded fan-out of the last layer (actual fan-outs <= NO)
 // XP: the strip's observations are prefetched into registers (fan-in <= 12)
-// HB = 64-wide blocks of the hidden layer: 1 everywhere except the one-hidden-layer case (D == 2) with a
-// fan-in of at most 4, where a hidden layer of up to 256 units (the reference's own ActorCriticNet / A2CNet
-// width, ppo_controller.py:14) is walked block by block inside the wave: that shape has no square product at
-// all, only layer 0, the last layer's dot product and their transposes, each per block.
-template <int D, int KB0, int NO, bool XP, int HB = 1>
+// (hidden layers of at most 64 units; one wider hidden layer over a small fan-in is k_ac_learn_wide's)
+template <int D, int KB0, int NO, bool XP>
 __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
-  static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
   constexpr int NW = 4, NT = 64 * NW;                // one wave per SIMD, with the whole register file
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;             // floats of the x tile (+ a dummy slot for idle prefetch lanes)
-  // WLV: 4 hidden blocks x 2 outputs.  The last layer's weight gradient is accumulated per feature from LDS tiles
-  // (rows_dwl) instead of per lane in 256 registers; the activation tile and the output-gradient rows it reads
-  // take the place D == 3 uses for h1^T (+ 4 rows)
-  constexpr bool WLV = HB * NO > 4;
-  constexpr int GOR = WLV ? 4 : 0;                   // rows of the output-gradient tile
-  constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0) + (WLV ? 64 * LDT : 0) + GOR * LDT;   // per-wave scratch
+  constexpr int WT = XT + 64 * LDT + (D == 3 ? 64 * LDT : 0);   // per-wave scratch
   constexpr int WTP = (WT + 3) & ~3;
   // One LDS array, carved by hand with the weights first: everything every strip reads (biases, last layer, W0, W1,
   // W1^T) then sits below 64 KB, within reach of a ds instruction's 16-bit offset from a lane's base register.
   // As separate arrays the compiler placed them behind the 120+ KB of tiles and kept one address register per read.
-  constexpr int OFF_B = 0;                                          // b0 (HB blocks), b1 (padded with zeros), bL
-  constexpr int OFF_WL = OFF_B + ((HB * 64 + 64 + 4 + 3) & ~3);
-  constexpr int OFF_W0 = OFF_WL + HB * NO * 64;
-  constexpr int OFF_W1 = OFF_W0 + ((HB * 64 * LDW0 + 3) & ~3);      // W1[n][k]
+  constexpr int OFF_B = 0;                                          // b0, b1 (padded with zeros), bL
+  constexpr int OFF_WL = OFF_B + ((64 + 64 + 4 + 3) & ~3);
+  constexpr int OFF_W0 = OFF_WL + NO * 64;
+  constexpr int OFF_W1 = OFF_W0 + ((64 * LDW0 + 3) & ~3);           // W1[n][k]
   constexpr int OFF_W1T = OFF_W1 + (D == 3 ? 64 * LDW : 0);         // W1^T: [k][n], the backward's A operand
   constexpr int OFF_T = OFF_W1T + (D == 3 ? 64 * LDW : 0);
   __shared__ __align__(16) float smem[OFF_T + NW * WTP];
@@ -533,11 +487,10 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int A = P.A;
 
   STAMP(0);
-  stage_weights<D, LDW0, NO, true, HB, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
+  stage_weights<D, LDW0, NO, true, 1, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
   float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
   float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
-  float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T; (WLV) the block's activations
-  float *sGo = sX + WT - GOR * LDT; // [GOR][LDT]  (WLV) gradient w.r.t. the outputs, one row per output
+  float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;   // rows >= K0 stay zero for good
   __syncthreads();
   STAMP(1);
@@ -545,33 +498,16 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // ---- per-wave persistent state
   f32x16 accW0[2][KB0];
   f32x16 accW1[2][2];
-  // NBQ: hidden blocks whose backward this workgroup runs.  4 blocks x 2 outputs would need 256 registers for
-  // the last layer's gradient accumulators alone, so that case is launched with gridDim.z = 2: every z runs
-  // the whole forward and the backward of its own two blocks (blocks qb0 .. qb0 + NBQ - 1), recomputing a
-  // block's activations there (RC below) instead of holding all four from the forward; the two z write
-  // disjoint entries of the same partial set, z = 0 also the scalars and the last layer's bias gradient.
-  // (kept for reference: the split is no longer taken -- WLV above removed the register pressure it answered)
-  constexpr int NBQ = HB;
-  constexpr bool RC = NBQ != HB;
-  const int qb0 = RC ? (int)blockIdx.z * NBQ : 0;
-  float dwlv[NBQ][NO];          // WLV: last-layer weight gradient of feature `lane` of block q
-  float vdb0[NBQ], vdb1 = 0.f;       // bias gradients of feature `lane` (of block q): row sums of the g tiles
-  // fan-in <= 4: dW0 of a block is 32 one-step products of v_mfma_f32_4x4x1 per strip (16 blocks of 4 features x 4
+  float vdb0 = 0.f, vdb1 = 0.f;      // bias gradients of feature `lane`: row sums of the g tiles
+  // fan-in <= 4: dW0 is 32 one-step products of v_mfma_f32_4x4x1 per strip (16 blocks of 4 features x 4
   // inputs: lane = feature on the A side, lane % 4 = input on the B side; 8 cycles each) instead of 32 padded
   // 32x32x2 MFMAs into accW0; element i of dw0m is dW0[4 (lane / 4) + i][lane % 4].  With a fan-in < 4 row 3 of the
   // x tile holds ones (W0's column 3 is zero, so the forward does not see them) and column 3 is the bias gradient.
-  const bool w0v = HB > 1 || (KB0 == 1 && XP && a.dims[0] <= 4);   // (HB > 1: the host has checked the fan-in)
+  const bool w0v = KB0 == 1 && XP && a.dims[0] <= 4;
   const bool ones3 = w0v && K0 < 4;
   if (ones3 && lane < 32) sX[3 * LDT + lane] = 1.f;
-  f32x4 dw0m[NBQ];
-  f32x16 dWL[WLV ? 1 : NBQ][NO][2];
-#pragma unroll
-  for (int qb = 0; qb < NBQ; ++qb) {
-#pragma unroll
-    for (int n = 0; n < NO; ++n) dwlv[qb][n] = 0.f;
-    vdb0[qb] = 0.f;
-    dw0m[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  f32x4 dw0m = {0.f, 0.f, 0.f, 0.f};
+  f32x16 dWL[NO][2];
   float dbL[NO];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -588,11 +524,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   for (int n = 0; n < NO; ++n) {
     dbL[n] = 0.f;
 #pragma unroll
-    for (int qb = 0; qb < (WLV ? 1 : NBQ); ++qb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dWL[qb][n][kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) dWL[n][kb][r] = 0.f;
   }
   float s_main = 0.f, s_ent = 0.f;
   float s_dls[NO];
@@ -701,32 +635,14 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
     PH(6);
 
     // ---- forward: h1, (h2), out
-    // RC: the blocks' activations are not held from forward to backward but recomputed per block in the
-    // backward (layer 0 over a fan-in <= 4 is two MFMA steps per tile)
-    constexpr int HQ = RC ? 1 : HB;
-    f32x16 h1q[HQ][2], h2[2];
-    f32x16 (&h1)[2] = h1q[0];
+    f32x16 h1[2], h2[2];
     float out[NO];
-    {
-      float pacc[NO];
-#pragma unroll
-      for (int n = 0; n < NO; ++n) pacc[n] = 0.f;
-#pragma unroll
-      for (int qb = 0; qb < HB; ++qb) {
-        fwd_layer0<LDW0>(h1q[RC ? 0 : qb], sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
-        if (RC) fwd_last_acc<NO>(pacc, h1q[0], sWL + qb * NO * 64, half);
-      }
-      PH(7);
-      if (D == 3) {
-        fwd_layer1(h2, h1, sW1, sB + HB * 64, half, r32);
-        fwd_last_acc<NO>(pacc, h2, sWL, half);
-      } else if (!RC) {
-#pragma unroll
-          for (int qb = 0; qb < HB; ++qb) fwd_last_acc<NO>(pacc, h1q[qb], sWL + qb * NO * 64, half);
-      }
-      PH(8);
-      fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
-    }
+    fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+    PH(7);
+    if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+    PH(8);
+    const f32x16 (&hl)[2] = D == 3 ? h2 : h1;
+    fwd_last<NO>(out, hl, sWL, sB + 128, half);
 
     PH(0);
     // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
@@ -737,21 +653,6 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
     for (int n = 0; n < NO; ++n)
       if (half == 0) dbL[n] += gout[n];
-#pragma unroll
-    for (int qb = 0; qb < NBQ; ++qb) {    // one pass per 64-wide block of the hidden layer (HB > 1: D == 2)
-    if (RC) fwd_layer0<LDW0>(h1q[0], sX, sW0 + (qb0 + qb) * 64 * LDW0, sB + (qb0 + qb) * 64, ksteps0, half, r32);
-    const f32x16 (&hl)[2] = D == 3 ? h2 : h1q[RC ? 0 : qb];
-    const float *sWLq = sWL + (qb0 + qb) * NO * 64;
-    if constexpr (WLV) {
-      // the block's activations and the output gradients as [.][row] tiles; lane = feature sums its row
-      put_tile(sH, hl, half, r32);
-      if (qb == 0 && half == 0) {
-#pragma unroll
-        for (int n = 0; n < NO; ++n) sGo[n * LDT + r32] = gout[n];
-      }
-      wave_lds_fence();
-      rows_dwl<NO>(sH + lane * LDT, sGo, dwlv[qb]);
-    }
     // ---- last layer backward (VALU): dWL, dbL partials; g = (WL^T gout) * (hl > 0)
     f32x16 g[2];
 #pragma unroll
@@ -761,15 +662,13 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int n = 0; n < NO; ++n) {
-          const float4 w4 = *(const float4 *)(sWLq + n * 64 + kb * 32 + 8 * q + 4 * half);
+          const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
           t[0] = fmaf(w4.x, gout[n], t[0]);
           t[1] = fmaf(w4.y, gout[n], t[1]);
           t[2] = fmaf(w4.z, gout[n], t[2]);
           t[3] = fmaf(w4.w, gout[n], t[3]);
-          if constexpr (!WLV) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dWL[qb][n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[qb][n][kb][4 * q + i]);
-          }
+          for (int i = 0; i < 4; ++i) dWL[n][kb][4 * q + i] = fmaf(gout[n], hl[kb][4 * q + i], dWL[n][kb][4 * q + i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = hl[kb][4 * q + i] > 0.f ? t[i] : 0.f;
@@ -828,12 +727,12 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          dw0m[qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4(gv[i], c), f4(xv[i], c), dw0m[qb], 0, 0, 0);
+          dw0m = __builtin_amdgcn_mfma_f32_4x4x1f32(f4(gv[i], c), f4(xv[i], c), dw0m, 0, 0, 0);
       if (!ones3) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s0 += gv[i].x; s1 += gv[i].y; s2 += gv[i].z; s3 += gv[i].w; }
-        vdb0[qb] += (s0 + s1) + (s2 + s3);
+        vdb0 += (s0 + s1) + (s2 + s3);
       }
     } else {
       const float *ga = sG + r32 * LDT + 4 * half, *xa = sX + r32 * LDT + 4 * half;
@@ -862,10 +761,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
         for (int kb = 0; kb < KB0; ++kb) xv[kb] = nx[kb];
       }
-      vdb0[0] += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
+      vdb0 += row_sum32(sG + lane * LDT);     // beside the dW0 MFMAs
     }
-    wave_lds_fence();     // the next block / strip overwrites sG (and sX)
-    }                     // hidden blocks
+    wave_lds_fence();     // the next strip overwrites sG and sX
     PH(3);
   }
   PH_OUT;
@@ -878,24 +776,15 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   // per-lane partial vectors dWL[n] -> per-feature sums over the wave's 32 rows: transposed
   // through the wave's own tile (the bias gradients vdb0 / vdb1 are per feature already)
   const float vec_db1 = vdb1;
-  float vec_wl[NBQ][NO];
-  {
-    float s;
+  float vec_wl[NO];
 #pragma unroll
-    for (int qb = 0; qb < NBQ; ++qb)
-#pragma unroll
-      for (int n = 0; n < NO; ++n) {
-        if constexpr (WLV) {
-          vec_wl[qb][n] = dwlv[qb][n];           // already per feature
-        } else {
-          put_tile(sG, dWL[qb][n], half, r32);
-          wave_lds_fence();
-          s = 0.f;
-          for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
-          vec_wl[qb][n] = s;
-          wave_lds_fence();
-        }
-      }
+  for (int n = 0; n < NO; ++n) {
+    put_tile(sG, dWL[n], half, r32);
+    wave_lds_fence();
+    float s = 0.f;
+    for (int r = 0; r < 32; ++r) s += sG[lane * LDT + r];
+    vec_wl[n] = s;
+    wave_lds_fence();
   }
   // scalars: wave sums (fixed butterfly order)
   float sc[2 + 2 * NO];
@@ -950,40 +839,36 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 #pragma unroll
     for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
   }
+  if (!ones3) {
+    vsum[(wave * VS + 0) * 64 + lane] = vdb0;
+  } else if ((lane & 3) == 3) {              // column 3 of the 4x4 products: the ones row
 #pragma unroll
-  for (int qb = 0; qb < NBQ; ++qb) {         // one round per 64-wide block of the hidden layer
-    if (qb) __syncthreads();                 // the previous round's sums are out
-    if (!ones3) {
-      vsum[(wave * VS + 0) * 64 + lane] = vdb0[qb];
-    } else if ((lane & 3) == 3) {              // column 3 of the 4x4 products: the ones row
+    for (int i = 0; i < 4; ++i) vsum[(wave * VS + 0) * 64 + 4 * (lane >> 2) + i] = dw0m[i];
+  }
+  vsum[(wave * VS + 1) * 64 + lane] = vec_db1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vsum[(wave * VS + 0) * 64 + 4 * (lane >> 2) + i] = dw0m[qb][i];
-    }
-    vsum[(wave * VS + 1) * 64 + lane] = vec_db1;
+  for (int n = 0; n < NO; ++n) vsum[(wave * VS + 2 + n) * 64 + lane] = vec_wl[n];
 #pragma unroll
-    for (int n = 0; n < NO; ++n) vsum[(wave * VS + 2 + n) * 64 + lane] = vec_wl[qb][n];
+  for (int i = 0; i < 4; ++i) vsum[(wave * VS + 2 + NO + (lane & 3)) * 64 + 4 * (lane >> 2) + i] = dw0m[i];
+  __syncthreads();
+  for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += NW) {
+    const int f = tid & 63;
+    float v = vsum[(0 * VS + sl) * 64 + f];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vsum[(wave * VS + 2 + NO + (lane & 3)) * 64 + 4 * (lane >> 2) + i] = dw0m[qb][i];
-    __syncthreads();
-    for (int sl = tid >> 6; sl < 2 + NO + (w0v ? 4 : 0); sl += NW) {
-      const int f = tid & 63, fq = (qb0 + qb) * 64 + f;
-      float v = vsum[(0 * VS + sl) * 64 + f];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) v += vsum[(w * VS + sl) * 64 + f];
-      if (sl >= 2 + NO) {
-        const int k = sl - 2 - NO;
-        if (fq < H1 && k < K0) part[a.poff[0] + fq * K0 + k] = v;
-      } else if (sl == 0) {
-        if (fq < H1) part[a.poff[0] + H1 * K0 + fq] = v;
-      } else if (sl == 1) {
-        if (D == 3 && f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
-      } else {
-        const int n = sl - 2;
-        if (fq < HL && n < NOr) part[a.poff[D - 1] + n * HL + fq] = v;
-      }
+    for (int w = 1; w < NW; ++w) v += vsum[(w * VS + sl) * 64 + f];
+    if (sl >= 2 + NO) {
+      const int k = sl - 2 - NO;
+      if (f < H1 && k < K0) part[a.poff[0] + f * K0 + k] = v;
+    } else if (sl == 0) {
+      if (f < H1) part[a.poff[0] + H1 * K0 + f] = v;
+    } else if (sl == 1) {
+      if (D == 3 && f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
+    } else {
+      const int n = sl - 2;
+      if (f < HL && n < NOr) part[a.poff[D - 1] + n * HL + f] = v;
     }
   }
-  if (tid < 2 + 2 * NO && (!RC || blockIdx.z == 0)) {
+  if (tid < 2 + 2 * NO) {
     float v = scal[tid];
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += scal[w * 16 + tid];
@@ -1183,16 +1068,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
           h[1] = MFMA(wop[q][1][s], xop[s], h[1]);
         }
         relu2(h);
-        fwd_last_acc2<NO>(pacc2, h, sWL + wl_off + q * NO * 64, half);
+        fwd_last_acc<NO>(pacc2, h, sWL + wl_off + q * NO * 64, half);
         // (one block at a time: left alone, the scheduler interleaves all blocks' products and parks their
         // accumulators in AGPRs, a copy in and a copy out per use)
         __builtin_amdgcn_sched_barrier(0);
       }
       PH(7);
-      float pacc[NO];
-#pragma unroll
-      for (int n = 0; n < NO; ++n) pacc[n] = pacc2[n].x + pacc2[n].y;
-      fwd_last_finish<NO>(out, pacc, sBL);
+      fwd_last_finish<NO>(out, pacc2, sBL);
     }
     PH(0);
     // ---- loss and its gradient w.r.t. out (arithmetic of k_ppo_loss)
@@ -1574,15 +1456,14 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};      // (two features per v_pk_fma_f32)
 #pragma unroll
           for (int n = 0; n < NO; ++n) {
             const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
-            t[0] = fmaf(w4.x, gout[n], t[0]);
-            t[1] = fmaf(w4.y, gout[n], t[1]);
-            t[2] = fmaf(w4.z, gout[n], t[2]);
-            t[3] = fmaf(w4.w, gout[n], t[3]);
+            t0 = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, f32x2{gout[n], gout[n]}, t0);
+            t1 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, f32x2{gout[n], gout[n]}, t1);
           }
+          const float t[4] = {t0.x, t0.y, t1.x, t1.y};
 #pragma unroll
           for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = h2[kb][4 * q + i] > 0.f ? t[i] : 0.f;
         }
@@ -1795,7 +1676,7 @@ struct InferArgs {
   float *value, *mean, *logp;
 };
 
-template <int D, int KB0, int NO, bool XP, int HB = 1>     // HB: as in k_ac_learn
+template <int D, int KB0, int NO, bool XP, int HB = 1>     // HB: 64-wide blocks of one wide hidden layer (D == 2, fan-in <= 4)
 __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
   static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
   constexpr int LDW0 = 32 * KB0 + 1;
@@ -1893,9 +1774,10 @@ __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
     fetch(strip + sstride);
     wave_lds_fence();
     f32x16 h1[2], h2[2];
-    float out[NO], pacc[NO];
+    float out[NO];
+    f32x2 pacc[NO];
 #pragma unroll
-    for (int n = 0; n < NO; ++n) pacc[n] = 0.f;
+    for (int n = 0; n < NO; ++n) pacc[n] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int qb = 0; qb < HB; ++qb) {     // the hidden layer block by block: only the dot product's partial sum stays
       fwd_layer0<LDW0>(h1, sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
