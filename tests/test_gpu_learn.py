@@ -134,6 +134,37 @@ def test_fused_forward_matches_torch(obs_size, A, hidden, B):
   assert m2 is None and l2 is None and torch.equal(v2, value)
 
 
+@pytest.mark.parametrize('obs_size,A,hidden,B', [(3, 1, (64, 64), 40001), (3, 1, (64, 64), 5000), (4, 2, (64, 64), 33000),
+                                                 (12, 1, (64, 48), 3000), (4, 1, (64,), 2000), (3, 1, (256,), 40001),
+                                                 (4, 2, (256,), 3000), (2, 1, (130,), 1000), (4, 2, (128,), 35000)])
+def test_forward_kernel_and_learner_forward_are_the_same_bits(obs_size, A, hidden, B):
+  """The forward-only kernel and the learner kernels evaluate a row to the same bit pattern (PPO's first-epoch ratio is
+  exactly 1; A2C's detached advantage uses the learner's own V).  Observable without a debug output: with the forward
+  kernel's values as the returns, the learner's critic loss and every critic gradient are exactly zero; with its
+  log-probs as the old ones, the ratio is 1 and the surrogate is the plain mean of the advantages, so clipping at a
+  ratio range of 1 +- 1e-30 (never active unless a ratio differs from 1) leaves the actor gradients unchanged."""
+  torch.manual_seed(B + obs_size)
+  ctl = PPOController(obs_size, A, device=DEV, hidden=hidden)
+  obs, act, _, adv, _ = _batch(obs_size, A, B, 3)
+  obs, act, adv = obs.to(DEV), act.to(DEV), adv.to(DEV)
+  value, _, logp = ctl._fused.forward(obs, act)
+  ret = value.view(B, 1).clone()
+  res = []
+  for clip in (0.2, 1e-30):
+    ctl._fused(obs, act, ret, logp, adv, clip, 0.5, 1e-3)
+    res.append(ctl._flat.grad.clone())
+  losses = ctl._fused(obs, act, ret, logp, adv, 0.2, 0.5, 1e-3).cpu()
+  assert float(losses[1]) == 0.0                                   # critic loss: (V - V)^2
+  off, ncrit = 0, 0
+  for name, p_ in ctl.ac_net.named_parameters():
+    if name.startswith('critic'):
+      assert not res[0][off:off + p_.numel()].any(), name          # critic gradients: exactly zero
+      ncrit += 1
+    off += p_.numel()
+  assert ncrit >= 4
+  assert torch.equal(res[0], res[1])                               # no ratio left the range [1 - 1e-30, 1 + 1e-30]
+
+
 def test_compute_return_fused_equals_general_path(monkeypatch):
   """compute_return_batched through the forward-only kernel == through the general path."""
   outs = []

@@ -1676,9 +1676,9 @@ struct InferArgs {
   float *value, *mean, *logp;
 };
 
-template <int D, int KB0, int NO, bool XP, int HB = 1>     // HB: 64-wide blocks of one wide hidden layer (D == 2, fan-in <= 4)
+template <int D, int KB0, int NO, bool XP>     // (hidden layers of at most 64 units; a wider one is k_ac_infer_wide's)
 __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
-  static_assert(HB == 1 || (D == 2 && KB0 == 1 && XP), "hidden blocks: one hidden layer, small fan-in only");
+  constexpr int HB = 1;
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;
   __shared__ __align__(16) float sW0[HB * 64 * LDW0];
@@ -1789,6 +1789,149 @@ __global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
       }
     }
     fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
+    if (valid && half == 0) {
+      if (net == 0) {
+        P.value[row] = out[0];
+      } else {
+#pragma unroll
+        for (int n = 0; n < NO; ++n)
+          if (n < A) {
+            if (P.mean) P.mean[row * A + n] = out[n];
+            if (P.logp) {
+              const float d = act[n] - out[n];
+              P.logp[row * A + n] = ((-(d * d)) / var2[n] - logsig[n]) - LOG_SQRT_2PI;   // Normal.log_prob
+            }
+          }
+      }
+    }
+    wave_lds_fence();     // the next strip overwrites sX
+  }
+}
+
+// The forward of k_ac_learn_wide alone (one wide hidden layer over a fan-in <= 4): the same operand registers, the
+// same k order ([W0 | b0] [x | 1]^T from C = 0) and the same packed dot product, so a value or log-prob computed here
+// is the bit pattern the learner kernel computes for that row (PPO's first-epoch ratio is exactly 1; A2C's detached
+// advantage uses the learner's own V).  Small LDS footprint and <= 128 registers: several workgroups per CU.
+template <int NO, int HB, bool K4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ac_infer_wide(InferArgs P) {
+  constexpr int NW = 4, NT = 64 * NW;
+  constexpr int XR = 6, XT = XR * LDT + 4;
+  __shared__ __align__(16) float sWL[HB * NO * 64];
+  __shared__ __align__(16) float sBL[4];
+  __shared__ __align__(16) float sT[NW * XT];
+  const int net = P.which[blockIdx.y];
+  const NetArgs &a = P.net[net];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5,
+            r32 = lane & 31;
+  const int K0 = a.dims[0], H1 = a.dims[1], NOr = a.dims[2];
+  const int64_t B = P.B;
+  const int A = P.A;
+  for (int e = tid; e < HB * NO * 64; e += NT) {
+    const int q = e / (NO * 64), r = e - q * NO * 64, n = r >> 6, k = q * 64 + (r & 63);
+    sWL[e] = (n < NOr && k < H1) ? a.w[1][n * H1 + k] : 0.f;
+  }
+  if (tid < 4) sBL[tid] = tid < NOr ? a.b[1][tid] : 0.f;
+  float *sX = sT + wave * XT;
+  for (int e = lane; e < XT; e += 64) sX[e] = 0.f;
+  if (lane < 32) sX[K0 * LDT + lane] = 1.f;
+  constexpr int KS = K4 ? 3 : 2;
+  float wop[HB][2][KS];
+#pragma unroll
+  for (int q = 0; q < HB; ++q)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int f = q * 64 + nb * 32 + r32;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + half;
+        float v = 0.f;
+        if (f < H1 && k < K0) v = a.w[0][f * K0 + k];
+        if (f < H1 && k == K0) v = a.b[0][f];
+        wop[q][nb][s] = v;
+      }
+    }
+  __syncthreads();
+
+  float var2[NO], logsig[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    var2[n] = 2.f; logsig[n] = 0.f;
+    if (net == 1 && P.logp && n < A) {
+      const float sigma = expf(P.log_std[n]);
+      var2[n] = 2.0f * (sigma * sigma);
+      logsig[n] = logf(sigma);
+    }
+  }
+  constexpr int XPF = 2;
+  const int nelem = 32 * K0;
+  int xoff[XPF];
+#pragma unroll
+  for (int j = 0; j < XPF; ++j) {
+    const int e = lane + 64 * j;
+    xoff[j] = e < nelem ? (e % K0) * LDT + e / K0 : XT - 4;
+  }
+  const bool want_lp = net == 1 && P.logp != nullptr;
+  const float *in_act[NO];
+  const int astr = want_lp ? A : 0;
+#pragma unroll
+  for (int n = 0; n < NO; ++n) in_act[n] = want_lp ? P.action + (n < A ? n : 0) : P.obs;
+  float xr[XPF], p_act[NO];
+  const int64_t nstrips = (B + 31) >> 5;
+  auto fetch = [&](int64_t strip) {
+    strip = strip < nstrips ? strip : nstrips - 1;
+    const int64_t row0 = strip << 5;
+    const int64_t row = row0 + r32;
+    const int64_t rowc = row < B ? row : B - 1;
+    const float *base = P.obs + row0 * K0;
+    const int64_t avail = (B - row0) * K0;
+    const int last = (int)(avail < nelem ? avail : nelem) - 1;
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) {
+      const int e = lane + 64 * j;
+      xr[j] = base[e < last ? e : last];
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) p_act[n] = in_act[n][rowc * astr];
+  };
+  const int64_t sstride = (int64_t)gridDim.x * NW;
+  int64_t strip = (int64_t)blockIdx.x * NW + wave;
+  fetch(strip);
+  for (; strip < nstrips; strip += sstride) {
+    const int64_t row = (strip << 5) + r32;
+    const bool valid = row < B;
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) sX[xoff[j]] = xr[j];
+    float act[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) act[n] = p_act[n];
+    fetch(strip + sstride);
+    wave_lds_fence();
+    float xop[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xop[s] = sX[(2 * s + half) * LDT + r32];
+    int wl_off = 0;      // (as in k_ac_learn_wide: keeps the last layer's rows out of registers)
+    asm volatile("" : "+v"(wl_off));
+    f32x2 pacc[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) pacc[n] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+      f32x16 h[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[nb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        h[0] = MFMA(wop[q][0][s], xop[s], h[0]);
+        h[1] = MFMA(wop[q][1][s], xop[s], h[1]);
+      }
+      relu2(h);
+      fwd_last_acc<NO>(pacc, h, sWL + wl_off + q * NO * 64, half);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float out[NO];
+    fwd_last_finish<NO>(out, pacc, sBL);
     if (valid && half == 0) {
       if (net == 0) {
         P.value[row] = out[0];
@@ -2113,8 +2256,11 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
   }
   P.obs = obs; P.action = action; P.log_std = log_std; P.B = B; P.A = want_actor ? A : 1;
   P.value = value; P.mean = mean; P.logp = logp;
+  int hmax = 0;
+  for (int i = 0; i < ny; ++i) hmax = P.net[P.which[i]].dims[1] > hmax ? P.net[P.which[i]].dims[1] : hmax;
+  const bool wide = D == 2 && hmax > 64;
   const int64_t need = trl_cdiv(trl_cdiv(B, 32), 4);
-  const int64_t cap = 768 / ny;      // ~3 workgroups per CU over the launch
+  const int64_t cap = (wide ? 1024 : 768) / ny;      // ~3 workgroups per CU over the launch (4 of the wide kernel's)
   const dim3 grid((unsigned)(need < cap ? need : cap), (unsigned)ny), block(256);
   const int KB0 = K0 <= 32 ? 1 : 2, NOv = (!want_actor || A <= 1) ? 1 : (A <= 2 ? 2 : 4);
   hipStream_t st = (hipStream_t)stream;
@@ -2124,18 +2270,14 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
     if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_infer<d, kb, no, kb == 1>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_infer<d, kb, no, false>), grid, block, 0, st, P);               \
   }
-  int hmax = 0;
-  for (int i = 0; i < ny; ++i) hmax = P.net[P.which[i]].dims[1] > hmax ? P.net[P.which[i]].dims[1] : hmax;
-  if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): blocks of 64
-    if (hmax <= 128) {
-      if (NOv == 1) hipLaunchKernelGGL((k_ac_infer<2, 1, 1, true, 2>), grid, block, 0, st, P);
-      else if (NOv == 2) hipLaunchKernelGGL((k_ac_infer<2, 1, 2, true, 2>), grid, block, 0, st, P);
-      else hipLaunchKernelGGL((k_ac_infer<2, 1, 4, true, 2>), grid, block, 0, st, P);
-    } else {
-      if (NOv == 1) hipLaunchKernelGGL((k_ac_infer<2, 1, 1, true, 4>), grid, block, 0, st, P);
-      else if (NOv == 2) hipLaunchKernelGGL((k_ac_infer<2, 1, 2, true, 4>), grid, block, 0, st, P);
-      else hipLaunchKernelGGL((k_ac_infer<2, 1, 4, true, 4>), grid, block, 0, st, P);
-    }
+  if (wide) {     // wide single hidden layer (fill_net has checked fan-in <= 4): blocks of 64
+#define TRL_WIDE_CASE(no, hb)                                                                     \
+  if (NOv == no && (hmax <= 128 ? 2 : 4) == hb) {                                                  \
+    if (K0 == 4) hipLaunchKernelGGL((k_ac_infer_wide<no, hb, true>), grid, block, 0, st, P);       \
+    else hipLaunchKernelGGL((k_ac_infer_wide<no, hb, false>), grid, block, 0, st, P);             \
+  }
+    TRL_WIDE_CASE(1, 2) TRL_WIDE_CASE(2, 2) TRL_WIDE_CASE(4, 2) TRL_WIDE_CASE(1, 4) TRL_WIDE_CASE(2, 4) TRL_WIDE_CASE(4, 4)
+#undef TRL_WIDE_CASE
   } else {
   TRL_INFER_CASE(2, 1, 1) TRL_INFER_CASE(2, 1, 2) TRL_INFER_CASE(2, 1, 4)
   TRL_INFER_CASE(2, 2, 1) TRL_INFER_CASE(2, 2, 2) TRL_INFER_CASE(2, 2, 4)
