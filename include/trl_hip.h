@@ -371,7 +371,10 @@ int trl_a2c_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
  *   value [B] (needs critic), mean [B, A], logp [B, A] = Normal(mean, exp(log_std)).log_prob(action)
  *   per dimension (need actor; logp also action [B, A] and log_std [A]); any output may be NULL.
  * Depth 2 or 3, widths <= 64, 1 <= A <= 4; one hidden layer (depth 2) over at most 4 observations
- * may be up to 256 wide (the width ppo_controller.py:14 builds). */
+ * may be up to 256 wide (the width ppo_controller.py:14 builds).
+ * A row's value / mean / log-prob is the bit pattern trl_ppo_learn_fused / trl_a2c_learn_fused compute for
+ * it on the same networks (a first-epoch PPO ratio is exactly 1).  Pass the actor's action size in A even
+ * when only `value` is asked for: it selects the kernel variant whose forward is the learner's. */
 int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
                           const float *obs, const float *action, int64_t B, int32_t A, float *value, float *mean,
                           float *logp, void *stream);

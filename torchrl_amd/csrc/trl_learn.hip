@@ -2140,7 +2140,9 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
   // two hidden layers over a fan-in <= 4 and enough strips to keep 1024 wave pairs busy: the role-split kernel
   bool pairk = critic->depth == 3 && critic->dims[0] <= 4 && A <= 2 && B >= 8 * 32 * 128;
+  bool onewide = true;     // one hidden layer <= 64 wide over a fan-in <= 4: k_ac_learn_wide with one block
 #ifdef TRL_TUNING
+  if (const char *e = getenv("TRL_LEARN_ONEWIDE")) onewide = atoi(e) != 0;       // A/B runs of tools/ only
   if (const char *e = getenv("TRL_LEARN_NW")) pairk = pairk && atoi(e) != 4;     // A/B runs of tools/ only
   if (const char *e = getenv("TRL_LEARN_PRIO")) P.tune_prio = atoi(e);
 #endif
@@ -2182,14 +2184,15 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   if (pairk) {
     if (NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair<1>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_ac_learn_pair<2>), grid, block, 0, st, P);
-  } else if (D == 2 && hmax > 64) {     // wide single hidden layer (fill_net has checked fan-in <= 4): 2 or 4 blocks of 64
+  } else if (D == 2 && (hmax > 64 || (onewide && critic->dims[0] <= 4 && NOv <= 2))) {
+    // one hidden layer over a fan-in <= 4 (fill_net has checked the fan-in of the wide ones): 1, 2 or 4 blocks of 64
     TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
 #define TRL_WIDE_CASE(no, hb)                                                                     \
-  if (NOv == no && (hmax <= 128 ? 2 : 4) == hb) {                                                  \
+  if (NOv == no && (hmax <= 64 ? 1 : (hmax <= 128 ? 2 : 4)) == hb) {                               \
     if (critic->dims[0] == 4) hipLaunchKernelGGL((k_ac_learn_wide<no, hb, true>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_learn_wide<no, hb, false>), grid, block, 0, st, P);             \
   }
-    TRL_WIDE_CASE(1, 2) TRL_WIDE_CASE(2, 2) TRL_WIDE_CASE(1, 4) TRL_WIDE_CASE(2, 4)
+    TRL_WIDE_CASE(1, 1) TRL_WIDE_CASE(2, 1) TRL_WIDE_CASE(1, 2) TRL_WIDE_CASE(2, 2) TRL_WIDE_CASE(1, 4) TRL_WIDE_CASE(2, 4)
 #undef TRL_WIDE_CASE
   } else {
   TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
@@ -2258,7 +2261,10 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
   P.value = value; P.mean = mean; P.logp = logp;
   int hmax = 0;
   for (int i = 0; i < ny; ++i) hmax = P.net[P.which[i]].dims[1] > hmax ? P.net[P.which[i]].dims[1] : hmax;
-  const bool wide = D == 2 && hmax > 64;
+  // one hidden layer over a fan-in <= 4: the learner's own forward (k_ac_learn_wide: any width up to 256; at most 64 wide
+  // only when the learner takes that kernel too, i.e. at most two actions -- A is read for this even when only the value
+  // is asked for)
+  const bool wide = D == 2 && (hmax > 64 || (K0 <= 4 && (A < 1 || A <= 2)));
   const int64_t need = trl_cdiv(trl_cdiv(B, 32), 4);
   const int64_t cap = (wide ? 1024 : 768) / ny;      // ~3 workgroups per CU over the launch (4 of the wide kernel's)
   const dim3 grid((unsigned)(need < cap ? need : cap), (unsigned)ny), block(256);
@@ -2272,10 +2278,11 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
   }
   if (wide) {     // wide single hidden layer (fill_net has checked fan-in <= 4): blocks of 64
 #define TRL_WIDE_CASE(no, hb)                                                                     \
-  if (NOv == no && (hmax <= 128 ? 2 : 4) == hb) {                                                  \
+  if (NOv == no && (hmax <= 64 ? 1 : (hmax <= 128 ? 2 : 4)) == hb) {                               \
     if (K0 == 4) hipLaunchKernelGGL((k_ac_infer_wide<no, hb, true>), grid, block, 0, st, P);       \
     else hipLaunchKernelGGL((k_ac_infer_wide<no, hb, false>), grid, block, 0, st, P);             \
   }
+    TRL_WIDE_CASE(1, 1) TRL_WIDE_CASE(2, 1)
     TRL_WIDE_CASE(1, 2) TRL_WIDE_CASE(2, 2) TRL_WIDE_CASE(4, 2) TRL_WIDE_CASE(1, 4) TRL_WIDE_CASE(2, 4) TRL_WIDE_CASE(4, 4)
 #undef TRL_WIDE_CASE
   } else {
