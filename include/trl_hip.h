@@ -404,6 +404,15 @@ int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_desc *critic, 
                          const trl_adam_args *critic_opt, float *target_actor_flat, float *target_critic_flat,
                          double tau, void *ws, void *stream);
 
+/* No counterpart in the reference (a switch for tests and measurements).  trl_ddpg_learn_fused issues its chain of
+ * phases as ONE launch (every workgroup walks the phases, a device-wide barrier between two of them; data handed
+ * from phase to phase goes through agent-scope accesses) unless the optimizer state lives on the device (graph
+ * capture).  on = 0: one launch per phase, as before; the two forms give the same bits.  The one-launch form keeps,
+ * per `ws` pointer, 256 B of device memory and a small ring of pinned host memory for the phase tables, allocated at
+ * the first call with that workspace and kept until the process ends; calls that share a `ws` must be on one stream
+ * (they already must: they share the scratch).  Process-wide; default on. */
+void trl_offpolicy_set_chain(int32_t on);
+
 /* DQNController.learn up to the optimizer step (dqn_controller.py:61-83; the periodic hard sync
  * of :85-86 stays trl_polyak with tau = 1) as 6 launches: q_net(obs), target_net(next_obs) and, for
  * Double-DQN, q_net(next_obs) (QNet, models.py:6-24); the TD target and loss (trl_td_loss); the

@@ -141,6 +141,34 @@ def test_ddpg_fused_huber_and_reproducible():
   assert abs(outs[0][0] - float(exp)) <= 1e-5 * abs(float(exp)) + 1e-7
 
 
+@pytest.mark.parametrize('S,A,hidden,B', [(3, 1, 256, 128), (17, 6, (128, 256), 256), (4, 3, 32, 16)])
+def test_ddpg_one_launch_chain_is_the_launch_chain_bit_for_bit(S, A, hidden, B):
+  """trl_ddpg_learn_fused as ONE launch (device-wide barriers between the phases, coherent accesses for what a phase
+  hands to the next) against one launch per phase (trl_offpolicy_set_chain(0)): five consecutive steps, each seeing
+  the earlier updates -- losses, all four networks' weights and both optimizers' moments, bit for bit."""
+  from torchrl_amd import _lib
+  outs = []
+  try:
+    for chain in (1, 0):
+      _lib.lib().trl_offpolicy_set_chain(chain)
+      rs = np.random.RandomState(S + B)
+      torch.manual_seed(S * 7 + B)
+      ctl = DDPGController(S, A, -1.0, 1.0, actor_lr=1e-3, critic_lr=1e-3, tau=0.05, device=DEV, hidden=hidden)
+      for net in (ctl.actor, ctl.critic, ctl.target_actor, ctl.target_critic):
+        _perturb(net, rs, 0.05)
+      losses = []
+      for _ in range(5):
+        info = ctl.learn(*[t.to(DEV) for t in _batch(rs, B, S, A)])
+        losses.append((float(info['actor_loss']), float(info['critic_loss'])))
+      torch.cuda.synchronize()
+      outs.append((losses, [t.data.clone() for t in (ctl._actor, ctl._critic, ctl._target_actor, ctl._target_critic)]))
+  finally:
+    _lib.lib().trl_offpolicy_set_chain(1)
+  assert outs[0][0] == outs[1][0]
+  for a, b in zip(outs[0][1], outs[1][1]):
+    assert torch.equal(a, b)
+
+
 DQN_SHAPES = [(4, 2, 128, 256), (4, 2, 128, 32), (8, 6, (64, 32), 48), (33, 18, (256, 128), 128)]
 
 

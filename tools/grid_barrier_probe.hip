@@ -4,6 +4,15 @@
 //   hipcc --offload-arch=gfx950 -O3 -o tools/bin/grid_barrier_probe tools/grid_barrier_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#ifdef RELAXED
+#define ORD_REL __ATOMIC_RELAXED
+#define ORD_ACQ __ATOMIC_RELAXED
+#define ORD_AR __ATOMIC_RELAXED
+#else
+#define ORD_REL __ATOMIC_RELEASE
+#define ORD_ACQ __ATOMIC_ACQUIRE
+#define ORD_AR __ATOMIC_ACQ_REL
+#endif
 #ifndef SLEEP
 #define SLEEP 2
 #endif
@@ -18,16 +27,16 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned &gen, unsig
     const unsigned gsize = nwg / NG + (g < nwg % NG ? 1 : 0);
     const unsigned ngroups = nwg < NG ? nwg : NG;
     bool last = false;
-    if (__hip_atomic_fetch_add(bar + 32 * (2 + g), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+    if (__hip_atomic_fetch_add(bar + 32 * (2 + g), 1u, ORD_REL, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
       __hip_atomic_store(bar + 32 * (2 + g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+      last = __hip_atomic_fetch_add(bar, 1u, ORD_AR, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
     }
     if (last) {
       __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(bar + 32, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(bar + 32, want, ORD_REL, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       for (int spin = 0; spin < (1 << 22); ++spin) {
-        if ((int)(__hip_atomic_load(bar + 32, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+        if ((int)(__hip_atomic_load(bar + 32, ORD_ACQ, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
         __builtin_amdgcn_s_sleep(SLEEP);
       }
     }
@@ -47,8 +56,16 @@ __global__ __launch_bounds__(256) void k_probe(unsigned *bar, float *buf, int nb
     // a phase's worth of dependent traffic: read what another workgroup wrote in the previous phase
     if (work) {
       const int src = (me + 256 * 37 * (b + 1)) % n;
+#ifdef RELAXED
+      // the exchanged data itself goes through agent-scope accesses (sc1: coherent across the XCDs' L2s), so the
+      // barrier needs no cache write-back / invalidate, only the stores' completion
+      acc += __hip_atomic_load(buf + (b & 1) * n + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(buf + ((b + 1) & 1) * n + me, acc + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) lgkmcnt(0) expcnt(0): the store has left the CU
+#else
       acc += buf[(b & 1) * n + src];
       buf[((b + 1) & 1) * n + me] = acc + 1.f;
+#endif
     }
     grid_barrier(bar, gen, gridDim.x);
   }

@@ -24,7 +24,12 @@
 // updates them; nothing inside one launch reads a parameter another workgroup of it writes.
 // Reductions have a fixed order, so a step is bitwise reproducible run to run.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
+#include <unordered_map>
 
 #include "trl_common.h"
 
@@ -84,20 +89,71 @@ struct Update {
   int mode;
 };
 
+// (one-launch chain only) a phase that is not a set of tiles: the DDPG losses, run by workgroup 0
+struct LossArgs {
+  const float *cur, *q_pi, *nq, *reward, *done;
+  int B, kind;
+  float gamma, hdelta;
+  float *dcur, *losses_out;
+};
+
 struct PhaseArgs {
   Tile t[MAX_TILES];
   Update u[2];
   int nt;
+  int wgs;            // (chain) workgroups' worth of tiles in this phase; 0: the losses entry
+  LossArgs L;
 };
 
-__device__ __forceinline__ f4v ld4(const float *p) { return *reinterpret_cast<const f4v *>(p); }
+// Every pointer of a Tile is global memory.  Said explicitly: in k_chain the tile descriptions come out of LDS and the
+// compiler would otherwise take the pointers for generic ones (flat_ instructions: both memory counters, more waits).
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) f4v gf4v;
+__device__ __forceinline__ const gfloat *gm(const float *p) { return (const gfloat *)p; }
+__device__ __forceinline__ gfloat *gm(float *p) { return (gfloat *)p; }
+__device__ __forceinline__ f4v ld4(const float *p) { return *(const gf4v *)p; }
+__device__ __forceinline__ float ld1(const float *p) { return *gm(p); }
+// x where `on`, else a zero -- as a product with 1.0 or 0.0.  Written `on ? x : 0.f` (or as a bit mask, which the
+// compiler turns back into that select) the LOAD of x is sunk under a branch on `on` and waited for there, one load at
+// a time (seen in the ISA: saveexec / load / vmcnt(0) per element).  Every address here is clamped to a valid, finite
+// element, so the loads can all be in flight together; a product's sign of zero does not reach a sum that starts at +0.
+__device__ __forceinline__ float keep(float x, bool on) { return x * (on ? 1.0f : 0.0f); }
+__device__ __forceinline__ f4v keep(f4v x, bool on) {
+  f4v r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) r[c] = keep(x[c], on);
+  return r;
+}
 
+// COH (the one-launch chain, k_chain): what one phase writes and a later phase of the SAME launch reads is stored
+// write-through at agent scope (sc1), so that it is in memory, past the writer's XCD's L2, once the store is
+// acknowledged; the barrier between two phases then needs no L2 write-back / invalidate, which is what makes it
+// cheaper than a kernel boundary (tools/grid_barrier_probe.hip: 1.7-2.5 us against 11-19 us with release / acquire,
+// ~7 us for a launch).  The READS stay plain, L2-cached 16 B loads: a reader's L2 or L1 could only hold a stale copy of
+// a line it had fetched earlier in this launch, and no line of these buffers is read before the phase that writes it
+// (every buffer is written whole by one phase, buffers are 256 B apart, and a launch starts with clean caches).
+// Agent-scope LOADS were measured and cost 3-4 us per tile (every operand fetched from memory, four dwords at a time).
+template <bool COH>
+__device__ __forceinline__ float ldf(const float *p) {
+  return *gm(p);
+}
+template <bool COH>
+__device__ __forceinline__ f4v ldv(const float *p) {
+  return ld4(p);
+}
+template <bool COH>
+__device__ __forceinline__ void stf(float *p, float v) {
+  if (COH) __hip_atomic_store(gm(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *gm(p) = v;
+}
+
+template <bool COH>
 __device__ __forceinline__ f4v grad_row4(const Grad &G, int i, int k, int Kg, bool virt) {
-  if (!virt) return ld4(G.g + (size_t)i * G.ld + k);
-  const f4v h = ld4(G.h + (size_t)i * Kg + k);
+  if (!virt) return ldv<COH>(G.g + (size_t)i * G.ld + k);
+  const f4v h = ldv<COH>(G.h + (size_t)i * Kg + k);
   f4v acc = {0.f, 0.f, 0.f, 0.f};
   for (int a = 0; a < G.As; ++a) {
-    const float s = G.seed ? G.seed[(size_t)i * G.As + a] : G.cseed;
+    const float s = G.seed ? ldf<COH>(G.seed + (size_t)i * G.As + a) : G.cseed;
     const f4v w = ld4(G.w2 + (size_t)a * Kg + k);
     acc += s * w;
   }
@@ -107,21 +163,23 @@ __device__ __forceinline__ f4v grad_row4(const Grad &G, int i, int k, int Kg, bo
   return r;
 }
 
+template <bool COH>
 __device__ __forceinline__ float grad_at(const Grad &G, int i, int m, int Kg, bool virt) {
-  if (!virt) return G.g[(size_t)i * G.ld + m];
-  const float h = G.h[(size_t)i * Kg + m];
+  if (!virt) return ldf<COH>(G.g + (size_t)i * G.ld + m);
+  const float h = ldf<COH>(G.h + (size_t)i * Kg + m);
   float acc = 0.f;
   for (int a = 0; a < G.As; ++a) {
-    const float s = G.seed ? G.seed[(size_t)i * G.As + a] : G.cseed;
-    acc += s * G.w2[(size_t)a * Kg + m];
+    const float s = G.seed ? ldf<COH>(G.seed + (size_t)i * G.As + a) : G.cseed;
+    acc += s * ld1(G.w2 + (size_t)a * Kg + m);
   }
   return h > 0.f ? acc : 0.f;
 }
 
 // X = [x1 | x2] at (row i, column k), k < K1 + K2
+template <bool COH>
 __device__ __forceinline__ float cat_at(const Tile &T, int i, int k) {
   const float *p = k < T.K1 ? T.x1 + (size_t)i * T.K1 + k : T.x2 + (size_t)i * T.K2 + (k - T.K1);
-  return *p;
+  return ldf<COH>(p);
 }
 
 // One wave's share [kb, ke) of the reduction: operand quads for 64 k's are fetched before the 16
@@ -157,7 +215,7 @@ __device__ __forceinline__ void apply_update(const Update &U, int64_t off, float
   }
 }
 
-template <int TYPE, bool FLAG>   // FLAG: FWD -> fast loads;  DX / DW -> G is taken on the fly
+template <int TYPE, bool FLAG, bool COH>   // FLAG: FWD -> fast loads;  DX / DW -> G is taken on the fly
 __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int tn, int kb, int ke, int r, int q) {
   if (TYPE == T_FWD) {
     const int i = m0 + r;                    // batch row (B % 16 == 0: always valid)
@@ -168,20 +226,20 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
       const float *wb = T.w + (size_t)nc * K;
       const bool nok = n < T.N;
       return mma_range(kb, ke, q,
-          [&](int kk) { const bool ok = kk < ke; f4v v = ld4(xa + (ok ? kk : 0)); return ok ? v : f4v{0.f, 0.f, 0.f, 0.f}; },
-          [&](int kk) { const bool ok = kk < ke && nok; f4v v = ld4(wb + (kk < ke ? kk : 0)); return ok ? v : f4v{0.f, 0.f, 0.f, 0.f}; });
+          [&](int kk) { const bool ok = kk < ke; f4v v = ldv<COH>(xa + (ok ? kk : 0)); return keep(v, ok); },
+          [&](int kk) { const bool ok = kk < ke && nok; f4v v = ld4(wb + (kk < ke ? kk : 0)); return keep(v, ok); });
     }
     return mma_range(kb, ke, q,
         [&](int kk) {
           f4v v;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = cat_at(T, i, ok ? k : 0); v[c] = ok ? x : 0.f; }
+          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = cat_at<COH>(T, i, ok ? k : 0); v[c] = keep(x, ok); }
           return v;
         },
         [&](int kk) {
           f4v v;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = T.w[(size_t)nc * K + (ok ? k : 0)]; v[c] = (ok && n < T.N) ? x : 0.f; }
+          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = ld1(T.w + (size_t)nc * K + (ok ? k : 0)); v[c] = keep(x, ok && n < T.N); }
           return v;
         });
   }
@@ -192,14 +250,21 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
     return mma_range(kb, ke, q,
         [&](int kk) {
           const bool ok = kk < ke;
-          f4v v = grad_row4(T.G, i, ok ? kk : 0, T.K, FLAG);
-          if (wr && ok) *reinterpret_cast<f4v *>(T.gout + (size_t)i * T.K + kk) = v;
-          return ok ? v : f4v{0.f, 0.f, 0.f, 0.f};
+          f4v v = grad_row4<COH>(T.G, i, ok ? kk : 0, T.K, FLAG);
+          if (wr && ok) {
+            if (COH) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) stf<true>(T.gout + (size_t)i * T.K + kk + c, v[c]);
+            } else {
+              *(gf4v *)(T.gout + (size_t)i * T.K + kk) = v;
+            }
+          }
+          return keep(v, ok);
         },
         [&](int kk) {
           f4v v;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = T.w[(size_t)(ok ? k : 0) * T.ldw + T.woff + nc]; v[c] = (ok && n < T.N) ? x : 0.f; }
+          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = ld1(T.w + (size_t)(ok ? k : 0) * T.ldw + T.woff + nc); v[c] = keep(x, ok && n < T.N); }
           return v;
         });
   }
@@ -210,26 +275,20 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
       [&](int kk) {
         f4v v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = grad_at(T.G, ok ? i : 0, mc, T.M, FLAG); v[c] = (ok && m < T.M) ? x : 0.f; }
+        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = grad_at<COH>(T.G, ok ? i : 0, mc, T.M, FLAG); v[c] = keep(x, ok && m < T.M); }
         return v;
       },
       [&](int kk) {
         f4v v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = cat_at(T, ok ? i : 0, nc); v[c] = (ok && n < T.N) ? x : 0.f; }
+        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = cat_at<COH>(T, ok ? i : 0, nc); v[c] = keep(x, ok && n < T.N); }
         return v;
       });
 }
 
-__global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
-  __shared__ float red[4][256];
-  const int wg = blockIdx.x;
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < MAX_TILES; ++i)
-    if (i < P.nt && wg >= P.t[i].wg0) pi = i;
-  const Tile &T = P.t[pi];
-  const int tl = wg - T.wg0;
+// one 16 x 16 output tile of problem T (tile index tl within the problem) by the whole workgroup
+template <bool COH>
+__device__ __forceinline__ void phase_tile(const Tile &T, const Update &U, int tl, float (*red)[256]) {
   const int tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
   const int m0 = tm * 16, n0 = tn * 16;
   const int t = threadIdx.x, w = t >> 6, lane = t & 63, r = lane & 15, q = lane >> 4;
@@ -240,11 +299,11 @@ __global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
 
   f4v acc;
   if (T.type == T_FWD)
-    acc = T.fast ? tile_product<T_FWD, true>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_FWD, false>(T, m0, n0, tn, kb, ke, r, q);
+    acc = T.fast ? tile_product<T_FWD, true, COH>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_FWD, false, COH>(T, m0, n0, tn, kb, ke, r, q);
   else if (T.type == T_DX)
-    acc = virt ? tile_product<T_DX, true>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DX, false>(T, m0, n0, tn, kb, ke, r, q);
+    acc = virt ? tile_product<T_DX, true, COH>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DX, false, COH>(T, m0, n0, tn, kb, ke, r, q);
   else
-    acc = virt ? tile_product<T_DW, true>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DW, false>(T, m0, n0, tn, kb, ke, r, q);
+    acc = virt ? tile_product<T_DW, true, COH>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DW, false, COH>(T, m0, n0, tn, kb, ke, r, q);
 
   // lane (r, q), register c holds element (row 4 q + c, column r) of the wave's partial tile
 #pragma unroll
@@ -256,24 +315,23 @@ __global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
 
   if (T.type == T_FWD) {
     if (n < T.N) {
-      v += T.b[n];
+      v += ld1(T.b + n);
       if (T.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (T.act == ACT_TANH) v = tanhf(v);
-      T.y[(size_t)m * T.ldy + n] = v;
+      stf<COH>(T.y + (size_t)m * T.ldy + n, v);
     }
     return;
   }
   if (T.type == T_DX) {
     if (n < T.N) {
       if (T.act != ACT_NONE) {
-        const float hv = T.hin[(size_t)m * T.ldhin + n];
+        const float hv = ldf<COH>(T.hin + (size_t)m * T.ldhin + n);
         v = T.act == ACT_RELU ? (hv > 0.f ? v : 0.f) : v * (1.0f - hv * hv);
       }
-      T.y[(size_t)m * T.ldy + n] = v;
+      stf<COH>(T.y + (size_t)m * T.ldy + n, v);
     }
     return;
   }
-  const Update &U = P.u[T.upd];
   if (m < T.M && n < T.N) apply_update(U, T.w_off + (int64_t)m * T.N + n, v);
   if (tn != 0) return;
   // bias gradient of rows m0 .. m0 + 15: column sums of G over the batch, 16 row segments per column
@@ -282,7 +340,7 @@ __global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
     const int mm = m0 + col, mc = mm < T.M ? mm : 0;
     const int rps = T.K / 16;
     float s = 0.f;
-    for (int i = row * rps; i < (row + 1) * rps; ++i) s += grad_at(T.G, i, mc, T.M, virt);
+    for (int i = row * rps; i < (row + 1) * rps; ++i) s += grad_at<COH>(T.G, i, mc, T.M, virt);
     red[0][t] = s;
   }
   __syncthreads();
@@ -294,30 +352,120 @@ __global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
+  __shared__ float red[4][256];
+  const int wg = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TILES; ++i)
+    if (i < P.nt && wg >= P.t[i].wg0) pi = i;
+  const Tile &T = P.t[pi];
+  phase_tile<false>(T, P.u[T.upd], wg - T.wg0, red);
+}
+
 // y = reward + (1 - done) * gamma * next_q;  critic loss = mean(l(cur - y));  actor loss = -mean(q_pi)
 // (ddpg_controller.py:105-112), and the gradient of the critic loss at cur.  One workgroup.
-__global__ __launch_bounds__(256) void k_ddpg_losses(const float *__restrict__ cur, const float *__restrict__ q_pi,
-                                                     const float *__restrict__ nq, const float *__restrict__ reward,
-                                                     const float *__restrict__ done, int B, float gamma, int kind,
-                                                     float hdelta, float *__restrict__ dcur,
-                                                     float *__restrict__ losses_out) {
-  __shared__ float red[4];
-  const float invB = 1.0f / (float)B;
+template <bool COH>
+__device__ __forceinline__ void ddpg_losses_body(const LossArgs &L, float *red) {
+  const float invB = 1.0f / (float)L.B;
   float s_c = 0.f, s_a = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) {
-    const float y = reward[b] + ((1.0f - done[b]) * gamma) * nq[b];
-    const float td = cur[b] - y;
+  for (int b = threadIdx.x; b < L.B; b += 256) {
+    const float y = ld1(L.reward + b) + ((1.0f - ld1(L.done + b)) * L.gamma) * ldf<COH>(L.nq + b);
+    const float td = ldf<COH>(L.cur + b) - y;
     float g;
-    s_c += trl_loss_elem(td, kind, hdelta, &g);
-    dcur[b] = invB * g;
-    s_a += q_pi[b];
+    s_c += trl_loss_elem(td, L.kind, L.hdelta, &g);
+    stf<COH>(L.dcur + b, invB * g);
+    s_a += ldf<COH>(L.q_pi + b);
   }
   s_c = trl_block_sum<4>(s_c, red);
   s_a = trl_block_sum<4>(s_a, red);
   if (threadIdx.x == 0) {
-    losses_out[0] = -(s_a * invB);
-    losses_out[1] = s_c * invB;
+    L.losses_out[0] = -(s_a * invB);
+    L.losses_out[1] = s_c * invB;
   }
+}
+
+__global__ __launch_bounds__(256) void k_ddpg_losses(LossArgs L) {
+  __shared__ float red[4];
+  ddpg_losses_body<false>(L, red);
+}
+
+// ---- the whole chain in ONE launch: every workgroup walks the phases, taking the tiles wg, wg + gridDim.x, ... of each,
+// with a device-wide barrier between two phases.  All workgroups are resident (the host launches at most two per CU),
+// the waits are bounded (a launch that lost a workgroup ends with wrong numbers rather than hanging the GPU).
+// bar (32-dword lines): line 0 the arrival count, line 1 the generation.
+__device__ __forceinline__ void chain_barrier(unsigned *bar, unsigned &gen, int nsleep) {
+  __builtin_amdgcn_s_waitcnt(0);     // this thread's write-through stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned want = gen + 1;
+    if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_store(bar + 32, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if ((int)(__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+        for (int j = 0; j < nsleep; ++j) __builtin_amdgcn_s_sleep(4);     // (polls of idle workgroups slow the busy ones)
+      }
+    }
+    gen = want;
+  }
+  __syncthreads();
+}
+
+constexpr int MAX_PHASES = 12;
+
+__global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ table, int nphase, unsigned *bar, int nsleep) {
+  __shared__ float red[4][256];
+  __shared__ __align__(16) int tab[MAX_PHASES * (sizeof(PhaseArgs) / 4)];
+  static_assert(sizeof(PhaseArgs) % 4 == 0, "dword copy");
+  constexpr int PW = sizeof(PhaseArgs) / 4;
+  // the phase table (pinned host memory, written by the host for this launch) -> LDS, one round trip
+  for (int e = threadIdx.x; e < nphase * PW; e += 256) tab[e] = ((const int *)table)[e];
+  unsigned gen = 0;
+  if (threadIdx.x == 0) gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  for (int p = 0; p < nphase; ++p) {
+#ifdef TRL_TUNING      // diagnostic build: 100 MHz stamps of workgroup 0 at each phase's start and at its barrier
+    if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long *)(bar + 64))[2 * p] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const PhaseArgs &P = *(const PhaseArgs *)(tab + p * PW);
+    if (P.wgs == 0) {
+      if (blockIdx.x == 0) {
+        union { LossArgs l; int w[sizeof(LossArgs) / 4]; } L;
+        const int *lsrc = (const int *)&P.L;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(LossArgs) / 4); ++i) L.w[i] = __builtin_amdgcn_readfirstlane(lsrc[i]);
+        ddpg_losses_body<true>(L.l, &red[0][0]);
+      }
+    } else {
+      for (int wg = blockIdx.x; wg < P.wgs; wg += gridDim.x) {
+        int pi = 0;
+#pragma unroll
+        for (int i = 1; i < MAX_TILES; ++i)
+          if (i < P.nt && wg >= P.t[i].wg0) pi = i;
+        // the tile's description as scalars (it is the same for the whole workgroup)
+        union { Tile t; int w[sizeof(Tile) / 4]; } T;
+        const int *src = (const int *)&P.t[pi];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(Tile) / 4); ++i) T.w[i] = __builtin_amdgcn_readfirstlane(src[i]);
+        union { Update u; int w[sizeof(Update) / 4]; } U;
+        const int *usrc = (const int *)&P.u[T.t.upd];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(Update) / 4); ++i) U.w[i] = __builtin_amdgcn_readfirstlane(usrc[i]);
+        phase_tile<true>(T.t, U.u, wg - T.t.wg0, red);
+        __syncthreads();     // `red` is free for the next tile
+      }
+    }
+#ifdef TRL_TUNING
+    if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long *)(bar + 64))[2 * p + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (p + 1 < nphase) chain_barrier(bar, gen, nsleep);
+  }
+#ifdef TRL_TUNING
+  if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long *)(bar + 64))[2 * nphase] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -376,7 +524,108 @@ void add_dw(Phase &ph, int B, Grad G, int M, const float *x1, int K1, const floa
   T.G = G; T.x1 = x1; T.K1 = K1; T.x2 = x2; T.K2 = K2; T.w_off = w_off; T.b_off = b_off; T.upd = upd;
 }
 
+// ---- the one-launch chain's host state, one per caller workspace: a barrier block in device memory and a ring of
+// phase tables in pinned host memory (a slot is reused only after the launch that read it has finished)
+constexpr int CHAIN_SLOTS = 16;
+struct ChainState {
+  unsigned *bar = nullptr;          // device, 256 dwords, zeroed once; the barrier leaves it clean
+  PhaseArgs *tables = nullptr;      // pinned host: CHAIN_SLOTS x MAX_PHASES
+  hipEvent_t ev[CHAIN_SLOTS];
+  bool used[CHAIN_SLOTS];
+  uint64_t n = 0;
+  int max_wgs = 0;                  // resident-workgroup budget of the device: two per CU
+};
+std::mutex g_chain_mu;
+std::unordered_map<const void *, ChainState *> g_chains;
+int g_chain_on = 1;
+
+ChainState *chain_state(const char *fn, const void *ws) {
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  auto it = g_chains.find(ws);
+  if (it != g_chains.end()) return it->second;
+  ChainState *c = new ChainState();
+  int dev = 0, cus = 0;
+  bool ok = hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+            hipMalloc((void **)&c->bar, 256 * sizeof(unsigned)) == hipSuccess &&
+            hipMemset(c->bar, 0, 256 * sizeof(unsigned)) == hipSuccess &&
+            hipHostMalloc((void **)&c->tables, sizeof(PhaseArgs) * CHAIN_SLOTS * MAX_PHASES, hipHostMallocDefault) == hipSuccess;
+  for (int i = 0; ok && i < CHAIN_SLOTS; ++i) {
+    ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
+    c->used[i] = false;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    trl_set_error("%s: could not set up the one-launch chain (device / pinned allocation)", fn);
+    delete c;
+    return nullptr;
+  }
+  c->max_wgs = 2 * cus;
+  g_chains[ws] = c;
+  return c;
+}
+
+// a step's phases, in order; run as one launch each, or all in one launch (k_chain)
+struct Chain {
+  PhaseArgs ph[MAX_PHASES];
+  int n = 0;
+  void add(const Phase &p) { ph[n] = p.a; ph[n].wgs = p.wgs; ++n; }
+  void add_losses(const LossArgs &L) { memset(&ph[n], 0, sizeof(PhaseArgs)); ph[n].L = L; ph[n].wgs = 0; ++n; }
+};
+
+int run_launches(const Chain &c, hipStream_t st, const char *what) {
+  for (int i = 0; i < c.n; ++i) {
+    if (c.ph[i].wgs == 0) hipLaunchKernelGGL(k_ddpg_losses, dim3(1), dim3(256), 0, st, c.ph[i].L);
+    else hipLaunchKernelGGL(k_phase, dim3(c.ph[i].wgs), dim3(256), 0, st, c.ph[i]);
+    TRL_CHECK_LAUNCH(what);
+  }
+  return TRL_OK;
+}
+
+int run_chain(const Chain &c, const void *ws, hipStream_t st, const char *what) {
+  ChainState *cs = chain_state(what, ws);
+  if (!cs) return TRL_EHIP;
+  const int slot = (int)(cs->n++ % CHAIN_SLOTS);
+  if (cs->used[slot] && hipEventSynchronize(cs->ev[slot]) != hipSuccess) {    // (16 launches back: long finished)
+    trl_set_error("%s: waiting for an earlier launch of the chain failed", what);
+    return TRL_EHIP;
+  }
+  PhaseArgs *tab = cs->tables + (size_t)slot * MAX_PHASES;
+  memcpy(tab, c.ph, sizeof(PhaseArgs) * c.n);
+  int wgs = 1;
+  for (int i = 0; i < c.n; ++i) wgs = c.ph[i].wgs > wgs ? c.ph[i].wgs : wgs;
+  wgs = wgs < cs->max_wgs ? wgs : cs->max_wgs;
+#ifdef TRL_TUNING
+  if (const char *e = getenv("TRL_CHAIN_WGS")) wgs = atoi(e) < wgs ? atoi(e) : wgs;     // A/B runs of tools/ only
+#endif
+  int nsleep = 2;
+#ifdef TRL_TUNING
+  if (const char *e = getenv("TRL_CHAIN_SLEEP")) nsleep = atoi(e);
+#endif
+  hipLaunchKernelGGL(k_chain, dim3(wgs), dim3(256), 0, st, (const PhaseArgs *)tab, c.n, cs->bar, nsleep);
+  TRL_CHECK_LAUNCH(what);
+  if (hipEventRecord(cs->ev[slot], st) != hipSuccess) {
+    trl_set_error("%s: hipEventRecord failed", what);
+    return TRL_EHIP;
+  }
+  cs->used[slot] = true;
+#ifdef TRL_TUNING
+  if (getenv("TRL_CHAIN_STAMPS") && cs->n % 200 == 0) {      // (synchronises: diagnostics only)
+    unsigned long long h[2 * MAX_PHASES + 1];
+    if (hipMemcpy(h, cs->bar + 64, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "k_chain, %d workgroups; phase: tiles' workgroups, us of workgroup 0 in the phase, us to the next phase's start\n", wgs);
+      for (int i = 0; i < c.n; ++i)
+        fprintf(stderr, "  phase %2d: %4d  %6.2f  %6.2f\n", i, c.ph[i].wgs, (double)(h[2 * i + 1] - h[2 * i]) / 100.0,
+                (double)(h[2 * i + 2] - h[2 * i + 1]) / 100.0);
+      fprintf(stderr, "  total %6.2f us\n", (double)(h[2 * c.n] - h[0]) / 100.0);
+    }
+  }
+#endif
+  return TRL_OK;
+}
+
 int launch(Phase &ph, hipStream_t st, const char *what) {
+  ph.a.wgs = ph.wgs;
   hipLaunchKernelGGL(k_phase, dim3(ph.wgs), dim3(256), 0, st, ph.a);
   TRL_CHECK_LAUNCH(what);
   return TRL_OK;
@@ -481,6 +730,8 @@ struct DqnWs {
 
 }  // namespace
 
+extern "C" void trl_offpolicy_set_chain(int32_t on) { g_chain_on = on ? 1 : 0; }
+
 extern "C" int64_t trl_ddpg_learn_workspace_bytes(const trl_mlp_desc *actor, const trl_mlp_desc *critic, int64_t B) {
   if (!actor || !critic || B <= 0) return 0;
   return (int64_t)(DdpgWs(nullptr, actor, critic, (size_t)B).floats * sizeof(float));
@@ -532,48 +783,52 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
     if ((rc = trl_adam_prep_launch(fn, actor_opt->dev_state, st)) || (rc = trl_adam_prep_launch(fn, critic_opt->dev_state, st)))
       return rc;
   }
+  Chain ch;
   {  // layer 0 of actor(obs), target_actor(next_obs), critic(obs, action)
     Phase ph;
     add_fwd(ph, B, obs, S, nullptr, 0, ac->w[0], ac->b[0], Ha0, ACT_RELU, W.a_h0);
     add_fwd(ph, B, next_obs, S, nullptr, 0, ta->w[0], ta->b[0], Ha0, ACT_RELU, W.ta_h0);
     add_fwd(ph, B, obs, S, action, A, cr->w[0], cr->b[0], Hc0, ACT_RELU, W.c_h0);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {  // layer 1 of the same three
     Phase ph;
     add_fwd(ph, B, W.a_h0, Ha0, nullptr, 0, ac->w[1], ac->b[1], Ha1, ACT_RELU, W.a_h1);
     add_fwd(ph, B, W.ta_h0, Ha0, nullptr, 0, ta->w[1], ta->b[1], Ha1, ACT_RELU, W.ta_h1);
     add_fwd(ph, B, W.c_h0, Hc0, nullptr, 0, cr->w[1], cr->b[1], Hc1, ACT_RELU, W.c_h1);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {  // pi(obs), pi'(next_obs) (tanh), Q(obs, action)
     Phase ph;
     add_fwd(ph, B, W.a_h1, Ha1, nullptr, 0, ac->w[2], ac->b[2], A, ACT_TANH, W.a_pi);
     add_fwd(ph, B, W.ta_h1, Ha1, nullptr, 0, ta->w[2], ta->b[2], A, ACT_TANH, W.a_next);
     add_fwd(ph, B, W.c_h1, Hc1, nullptr, 0, cr->w[2], cr->b[2], 1, ACT_NONE, W.cur);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {  // critic(obs, pi(obs)) and target_critic(next_obs, pi'(next_obs)), three layers
     Phase ph;
     add_fwd(ph, B, obs, S, W.a_pi, A, cr->w[0], cr->b[0], Hc0, ACT_RELU, W.p_h0);
     add_fwd(ph, B, next_obs, S, W.a_next, A, tc->w[0], tc->b[0], Hc0, ACT_RELU, W.tc_h0);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {
     Phase ph;
     add_fwd(ph, B, W.p_h0, Hc0, nullptr, 0, cr->w[1], cr->b[1], Hc1, ACT_RELU, W.p_h1);
     add_fwd(ph, B, W.tc_h0, Hc0, nullptr, 0, tc->w[1], tc->b[1], Hc1, ACT_RELU, W.tc_h1);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {
     Phase ph;
     add_fwd(ph, B, W.p_h1, Hc1, nullptr, 0, cr->w[2], cr->b[2], 1, ACT_NONE, W.q_pi);
     add_fwd(ph, B, W.tc_h1, Hc1, nullptr, 0, tc->w[2], tc->b[2], 1, ACT_NONE, W.nq);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
-  hipLaunchKernelGGL(k_ddpg_losses, dim3(1), dim3(256), 0, st, W.cur, W.q_pi, W.nq, reward, done, B, (float)gamma,
-                     (int)kind, (float)huber_delta, W.dcur, losses_out);
-  TRL_CHECK_LAUNCH(fn);
+  {
+    LossArgs L;
+    L.cur = W.cur; L.q_pi = W.q_pi; L.nq = W.nq; L.reward = reward; L.done = done; L.B = B; L.kind = (int)kind;
+    L.gamma = (float)gamma; L.hdelta = (float)huber_delta; L.dcur = W.dcur; L.losses_out = losses_out;
+    ch.add_losses(L);
+  }
 
   const Grad G_p1 = g_virtual(nullptr, -1.0f / (float)B, 1, cr->w[2], W.p_h1);   // d(-mean Q)/d p_h1
   const Grad G_c1 = g_virtual(W.dcur, 0.f, 1, cr->w[2], W.c_h1);                 // d critic_loss / d c_h1
@@ -581,14 +836,14 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
     Phase ph;
     add_dx(ph, B, G_p1, Hc1, cr->w[1], Hc0, 0, Hc0, ACT_RELU, W.p_h0, Hc0, W.g_p0, nullptr);
     add_dx(ph, B, G_c1, Hc1, cr->w[1], Hc0, 0, Hc0, ACT_RELU, W.c_h0, Hc0, W.g_c0, nullptr);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {  // critic layer 1's gradient (+ update); actor path: through critic layer 0's action columns and the tanh
     Phase ph;
     ph.a.u[0] = Uc;
     add_dw(ph, B, G_c1, Hc1, W.c_h0, Hc0, nullptr, 0, c_off(cr->w[1]), c_off(cr->b[1]), 0);
     add_dx(ph, B, g_material(W.g_p0, Hc0), Hc0, cr->w[0], S + A, S, A, ACT_TANH, W.a_pi, A, W.dz2, nullptr);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {  // through actor layer 1 (keeping the masked outer product for the next launch); critic layers 0 and 2
     Phase ph;
@@ -597,7 +852,7 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
            W.g_a0, W.g_a1);
     add_dw(ph, B, g_material(W.g_c0, Hc0), Hc0, obs, S, action, A, c_off(cr->w[0]), c_off(cr->b[0]), 0);
     add_dw(ph, B, g_material(W.dcur, 1), 1, W.c_h1, Hc1, nullptr, 0, c_off(cr->w[2]), c_off(cr->b[2]), 0);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
   }
   {  // the actor's three layers
     Phase ph;
@@ -605,7 +860,14 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
     add_dw(ph, B, g_material(W.g_a1, Ha1), Ha1, W.a_h0, Ha0, nullptr, 0, a_off(ac->w[1]), a_off(ac->b[1]), 0);
     add_dw(ph, B, g_material(W.g_a0, Ha0), Ha0, obs, S, nullptr, 0, a_off(ac->w[0]), a_off(ac->b[0]), 0);
     add_dw(ph, B, g_material(W.dz2, A), A, W.a_h1, Ha1, nullptr, 0, a_off(ac->w[2]), a_off(ac->b[2]), 0);
-    if ((rc = launch(ph, st, fn))) return rc;
+    ch.add(ph);
+  }
+  // One launch for the whole chain, or one per phase.  The step counts of a captured graph live on the device and
+  // its capture must not meet the chain's host-side event wait, so graph mode keeps the launches.
+  if (g_chain_on && !actor_opt->dev_state) {
+    if ((rc = run_chain(ch, ws, st, fn))) return rc;
+  } else if ((rc = run_launches(ch, st, fn))) {
+    return rc;
   }
   return TRL_OK;
 }
