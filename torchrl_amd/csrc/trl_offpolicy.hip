@@ -147,15 +147,25 @@ __device__ __forceinline__ void stf(float *p, float v) {
   else *gm(p) = v;
 }
 
-template <bool COH>
+// AS1: one output (a critic's value, a one-dimensional action), the common case -- straight-line and branch-free (the
+// seed pointer's null test becomes arithmetic on a load from a valid address), so that a caller's loads for several
+// quads / rows are all issued before the first is waited for; a branch or a run-time loop between two loads keeps them
+// in separate blocks and the second is issued only after the first has come back.
+template <bool COH, bool AS1>
 __device__ __forceinline__ f4v grad_row4(const Grad &G, int i, int k, int Kg, bool virt) {
   if (!virt) return ldv<COH>(G.g + (size_t)i * G.ld + k);
   const f4v h = ldv<COH>(G.h + (size_t)i * Kg + k);
   f4v acc = {0.f, 0.f, 0.f, 0.f};
-  for (int a = 0; a < G.As; ++a) {
-    const float s = G.seed ? ldf<COH>(G.seed + (size_t)i * G.As + a) : G.cseed;
-    const f4v w = ld4(G.w2 + (size_t)a * Kg + k);
-    acc += s * w;
+  if (AS1) {
+    const float fs = G.seed ? 1.0f : 0.0f, cs = G.seed ? 0.0f : G.cseed;
+    const float s = ldf<COH>(G.seed ? G.seed + i : G.w2) * fs + cs;      // seed[i], or cseed (x * 1 + 0 and x * 0 + c are exact)
+    acc += s * ld4(G.w2 + k);
+  } else {
+    for (int a = 0; a < G.As; ++a) {
+      const float s = G.seed ? ldf<COH>(G.seed + (size_t)i * G.As + a) : G.cseed;
+      const f4v w = ld4(G.w2 + (size_t)a * Kg + k);
+      acc += s * w;
+    }
   }
   f4v r;
 #pragma unroll
@@ -163,14 +173,20 @@ __device__ __forceinline__ f4v grad_row4(const Grad &G, int i, int k, int Kg, bo
   return r;
 }
 
-template <bool COH>
+template <bool COH, bool AS1>
 __device__ __forceinline__ float grad_at(const Grad &G, int i, int m, int Kg, bool virt) {
   if (!virt) return ldf<COH>(G.g + (size_t)i * G.ld + m);
   const float h = ldf<COH>(G.h + (size_t)i * Kg + m);
   float acc = 0.f;
-  for (int a = 0; a < G.As; ++a) {
-    const float s = G.seed ? ldf<COH>(G.seed + (size_t)i * G.As + a) : G.cseed;
-    acc += s * ld1(G.w2 + (size_t)a * Kg + m);
+  if (AS1) {
+    const float fs = G.seed ? 1.0f : 0.0f, cs = G.seed ? 0.0f : G.cseed;
+    const float s = ldf<COH>(G.seed ? G.seed + i : G.w2) * fs + cs;
+    acc += s * ld1(G.w2 + m);
+  } else {
+    for (int a = 0; a < G.As; ++a) {
+      const float s = G.seed ? ldf<COH>(G.seed + (size_t)i * G.As + a) : G.cseed;
+      acc += s * ld1(G.w2 + (size_t)a * Kg + m);
+    }
   }
   return h > 0.f ? acc : 0.f;
 }
@@ -186,8 +202,8 @@ __device__ __forceinline__ float cat_at(const Tile &T, int i, int k) {
 // MFMAs that consume them.  Lane (r = lane & 15, q = lane >> 4) feeds row r of A and column r of B at
 // the four k's kk .. kk + 3, kk = kc + 16 u + 4 q -- the same k's on both sides, which is all the
 // instruction needs (it sums over its k slots; which k sits in which slot is free).
-template <class LA, class LB>
-__device__ __forceinline__ f4v mma_range(int kb, int ke, int q, LA load_a, LB load_b) {
+template <class LA, class LB, class SA>
+__device__ __forceinline__ f4v mma_range(int kb, int ke, int q, LA load_a, LB load_b, SA after_a) {
   f4v acc = {0.f, 0.f, 0.f, 0.f};
   for (int kc = kb; kc < ke; kc += 64) {
     f4v a[4], b[4];
@@ -197,6 +213,10 @@ __device__ __forceinline__ f4v mma_range(int kb, int ke, int q, LA load_a, LB lo
       a[u] = load_a(kk);
       b[u] = load_b(kk);
     }
+    // (what is done with an A quad besides the product -- the DX tiles' copy of it -- comes after ALL the loads have
+    // been issued: a store between two loads waits for the first and holds the second back)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) after_a(kc + 16 * u + 4 * q, a[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -205,17 +225,41 @@ __device__ __forceinline__ f4v mma_range(int kb, int ke, int q, LA load_a, LB lo
   return acc;
 }
 
-__device__ __forceinline__ void apply_update(const Update &U, int64_t off, float g) {
-  U.grad[off] = g;
-  if (U.mode >= UPD_ADAM) {
-    const TrlAdamScalars sc = U.dev ? *U.dev : U.s;
-    trl_adam_elem(U.param + off, U.grad + off, U.m + off, U.v + off, sc);
-    if (U.mode == UPD_ADAM_POLYAK)
-      U.target[off] = __fadd_rn(__fmul_rn(U.tau, U.param[off]), __fmul_rn(U.omt, U.target[off]));
+// A gradient element's update (Adam, then the Polyak average into the target network) with the element's optimizer
+// state read AHEAD of the product that yields the gradient: a tile is a chain of dependent memory round trips
+// (operands, product, state, stores), and this takes one out of the chain.
+struct AdamPre {
+  float p, m, v, t;
+};
+__device__ __forceinline__ AdamPre update_prefetch(const Update &U, int64_t off, bool on) {
+  AdamPre a = {0.f, 0.f, 0.f, 0.f};
+  if (on && U.mode >= UPD_ADAM) {
+    a.p = U.param[off]; a.m = U.m[off]; a.v = U.v[off];
+    if (U.mode == UPD_ADAM_POLYAK) a.t = U.target[off];
   }
+  return a;
+}
+__device__ __forceinline__ void apply_update(const Update &U, int64_t off, float g, const AdamPre &a) {
+  if (U.mode < UPD_ADAM) {
+    U.grad[off] = g;
+    return;
+  }
+  const TrlAdamScalars s = U.dev ? *U.dev : U.s;      // (trl_adam_elem's arithmetic, op for op)
+  float gi = g;
+  if (s.scale != 1.0f) gi = __fmul_rn(gi, s.scale);
+  if (s.clip > 0.f) gi = fminf(fmaxf(gi, -s.clip), s.clip);
+  U.grad[off] = gi;
+  const float mi = __fadd_rn(a.m, __fmul_rn(s.w1, __fsub_rn(gi, a.m)));
+  const float vi = __fadd_rn(__fmul_rn(a.v, s.beta2), __fmul_rn(__fmul_rn(s.c2, gi), gi));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), s.bc2_sqrt), s.eps);
+  const float pn = __fadd_rn(a.p, __fdiv_rn(__fmul_rn(s.neg_step, mi), denom));
+  U.param[off] = pn;
+  U.m[off] = mi;
+  U.v[off] = vi;
+  if (U.mode == UPD_ADAM_POLYAK) U.target[off] = __fadd_rn(__fmul_rn(U.tau, pn), __fmul_rn(U.omt, a.t));
 }
 
-template <int TYPE, bool FLAG, bool COH>   // FLAG: FWD -> fast loads;  DX / DW -> G is taken on the fly
+template <int TYPE, bool FLAG, bool COH, bool AS1 = false>   // FLAG: FWD -> fast loads;  DX / DW -> G is taken on the fly
 __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int tn, int kb, int ke, int r, int q) {
   if (TYPE == T_FWD) {
     const int i = m0 + r;                    // batch row (B % 16 == 0: always valid)
@@ -227,7 +271,8 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
       const bool nok = n < T.N;
       return mma_range(kb, ke, q,
           [&](int kk) { const bool ok = kk < ke; f4v v = ldv<COH>(xa + (ok ? kk : 0)); return keep(v, ok); },
-          [&](int kk) { const bool ok = kk < ke && nok; f4v v = ld4(wb + (kk < ke ? kk : 0)); return keep(v, ok); });
+          [&](int kk) { const bool ok = kk < ke && nok; f4v v = ld4(wb + (kk < ke ? kk : 0)); return keep(v, ok); },
+          [](int, const f4v &) {});
     }
     return mma_range(kb, ke, q,
         [&](int kk) {
@@ -241,7 +286,8 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
 #pragma unroll
           for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = ld1(T.w + (size_t)nc * K + (ok ? k : 0)); v[c] = keep(x, ok && n < T.N); }
           return v;
-        });
+        },
+        [](int, const f4v &) {});
   }
   if (TYPE == T_DX) {
     const int i = m0 + r;
@@ -250,8 +296,16 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
     return mma_range(kb, ke, q,
         [&](int kk) {
           const bool ok = kk < ke;
-          f4v v = grad_row4<COH>(T.G, i, ok ? kk : 0, T.K, FLAG);
-          if (wr && ok) {
+          return keep(grad_row4<COH, AS1>(T.G, i, ok ? kk : 0, T.K, FLAG), ok);
+        },
+        [&](int kk) {
+          f4v v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = ld1(T.w + (size_t)(ok ? k : 0) * T.ldw + T.woff + nc); v[c] = keep(x, ok && n < T.N); }
+          return v;
+        },
+        [&](int kk, const f4v &v) {      // the optional copy of G (rows of the first column of tiles write it)
+          if (wr && kk < ke) {
             if (COH) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) stf<true>(T.gout + (size_t)i * T.K + kk + c, v[c]);
@@ -259,13 +313,6 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
               *(gf4v *)(T.gout + (size_t)i * T.K + kk) = v;
             }
           }
-          return keep(v, ok);
-        },
-        [&](int kk) {
-          f4v v;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) { const int k = kk + c; const bool ok = k < ke; const float x = ld1(T.w + (size_t)(ok ? k : 0) * T.ldw + T.woff + nc); v[c] = keep(x, ok && n < T.N); }
-          return v;
         });
   }
   // T_DW: rows of the product = output features m, columns = input features n, reduction over the batch
@@ -275,7 +322,7 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
       [&](int kk) {
         f4v v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = grad_at<COH>(T.G, ok ? i : 0, mc, T.M, FLAG); v[c] = keep(x, ok && m < T.M); }
+        for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = grad_at<COH, AS1>(T.G, ok ? i : 0, mc, T.M, FLAG); v[c] = keep(x, ok && m < T.M); }
         return v;
       },
       [&](int kk) {
@@ -283,8 +330,20 @@ __device__ __forceinline__ f4v tile_product(const Tile &T, int m0, int n0, int t
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const int i = kk + c; const bool ok = i < ke; const float x = cat_at<COH>(T, ok ? i : 0, nc); v[c] = keep(x, ok && n < T.N); }
         return v;
-      });
+      },
+      [](int, const f4v &) {});
 }
+
+#ifdef TRL_TUNING      // diagnostic build: 100 MHz stamps inside workgroup 0's tile of each phase of k_chain
+__device__ unsigned long long g_dbg[16 * 8];
+__device__ int g_dbg_phase;
+#define DBG(k)                                                                                     \
+  do {                                                                                             \
+    if (COH && blockIdx.x == 0 && threadIdx.x == 0) g_dbg[(g_dbg_phase & 15) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define DBG(k)
+#endif
 
 // one 16 x 16 output tile of problem T (tile index tl within the problem) by the whole workgroup
 template <bool COH>
@@ -296,22 +355,59 @@ __device__ __forceinline__ void phase_tile(const Tile &T, const Update &U, int t
   const int kb = w * Kq;
   const int ke = min(T.K, kb + Kq);
   const bool virt = T.G.g == nullptr;
+  const bool as1 = T.G.As == 1;
+  const int row = t >> 4, col = t & 15;
+  const int m = m0 + row, n = n0 + col;
 
+  // a weight-gradient tile: the optimizer state of the tile's elements and (first tile of a row of tiles) the bias
+  // gradient's partial column sums are fetched / formed up front, beside the product's own operand loads
+  AdamPre pre_w = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f};
+  float sbias = 0.f;
+  DBG(0);
+  if (T.type == T_DW) {
+    pre_w = update_prefetch(U, T.w_off + (int64_t)m * T.N + n, m < T.M && n < T.N);
+    if (tn == 0) {
+      pre_b = update_prefetch(U, T.b_off + m0 + t, t < 16 && m0 + t < T.M);
+      // bias gradient of rows m0 .. m0 + 15: column sums of G over the batch, 16 row segments per column; eight rows'
+      // loads in flight at a time, added in row order
+      const int mm = m0 + col, mc = mm < T.M ? mm : 0;
+      const int rps = T.K / 16;
+      const int iend = (row + 1) * rps;
+      for (int i0 = row * rps; i0 < iend; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool on = i0 + j < iend;
+          const float x = (virt && as1) ? grad_at<COH, true>(T.G, on ? i0 + j : i0, mc, T.M, true)
+                                        : grad_at<COH, false>(T.G, on ? i0 + j : i0, mc, T.M, virt);
+          v[j] = keep(x, on);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sbias += v[j];
+      }
+    }
+  }
+
+  DBG(1);
   f4v acc;
   if (T.type == T_FWD)
     acc = T.fast ? tile_product<T_FWD, true, COH>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_FWD, false, COH>(T, m0, n0, tn, kb, ke, r, q);
   else if (T.type == T_DX)
-    acc = virt ? tile_product<T_DX, true, COH>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DX, false, COH>(T, m0, n0, tn, kb, ke, r, q);
+    acc = !virt ? tile_product<T_DX, false, COH>(T, m0, n0, tn, kb, ke, r, q)
+                : (as1 ? tile_product<T_DX, true, COH, true>(T, m0, n0, tn, kb, ke, r, q)
+                       : tile_product<T_DX, true, COH, false>(T, m0, n0, tn, kb, ke, r, q));
   else
-    acc = virt ? tile_product<T_DW, true, COH>(T, m0, n0, tn, kb, ke, r, q) : tile_product<T_DW, false, COH>(T, m0, n0, tn, kb, ke, r, q);
+    acc = !virt ? tile_product<T_DW, false, COH>(T, m0, n0, tn, kb, ke, r, q)
+                : (as1 ? tile_product<T_DW, true, COH, true>(T, m0, n0, tn, kb, ke, r, q)
+                       : tile_product<T_DW, true, COH, false>(T, m0, n0, tn, kb, ke, r, q));
 
   // lane (r, q), register c holds element (row 4 q + c, column r) of the wave's partial tile
 #pragma unroll
   for (int c = 0; c < 4; ++c) red[w][(4 * q + c) * 16 + r] = acc[c];
+  DBG(2);
   __syncthreads();
   float v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
-  const int row = t >> 4, col = t & 15;
-  const int m = m0 + row, n = n0 + col;
+  DBG(3);
 
   if (T.type == T_FWD) {
     if (n < T.N) {
@@ -332,24 +428,19 @@ __device__ __forceinline__ void phase_tile(const Tile &T, const Update &U, int t
     }
     return;
   }
-  if (m < T.M && n < T.N) apply_update(U, T.w_off + (int64_t)m * T.N + n, v);
+  if (m < T.M && n < T.N) apply_update(U, T.w_off + (int64_t)m * T.N + n, v, pre_w);
+  DBG(4);
   if (tn != 0) return;
-  // bias gradient of rows m0 .. m0 + 15: column sums of G over the batch, 16 row segments per column
   __syncthreads();
-  {
-    const int mm = m0 + col, mc = mm < T.M ? mm : 0;
-    const int rps = T.K / 16;
-    float s = 0.f;
-    for (int i = row * rps; i < (row + 1) * rps; ++i) s += grad_at<COH>(T.G, i, mc, T.M, virt);
-    red[0][t] = s;
-  }
+  red[0][t] = sbias;
   __syncthreads();
   if (t < 16 && m0 + t < T.M) {
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) s += red[0][g * 16 + t];
-    apply_update(U, T.b_off + m0 + t, s);
+    apply_update(U, T.b_off + m0 + t, s, pre_b);
   }
+  DBG(5);
 }
 
 __global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
@@ -428,7 +519,10 @@ __global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ tab
   __syncthreads();
   for (int p = 0; p < nphase; ++p) {
 #ifdef TRL_TUNING      // diagnostic build: 100 MHz stamps of workgroup 0 at each phase's start and at its barrier
-    if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long *)(bar + 64))[2 * p] = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ((unsigned long long *)(bar + 64))[2 * p] = __builtin_amdgcn_s_memrealtime();
+      g_dbg_phase = p;
+    }
 #endif
     const PhaseArgs &P = *(const PhaseArgs *)(tab + p * PW);
     if (P.wgs == 0) {
@@ -618,6 +712,13 @@ int run_chain(const Chain &c, const void *ws, hipStream_t st, const char *what) 
         fprintf(stderr, "  phase %2d: %4d  %6.2f  %6.2f\n", i, c.ph[i].wgs, (double)(h[2 * i + 1] - h[2 * i]) / 100.0,
                 (double)(h[2 * i + 2] - h[2 * i + 1]) / 100.0);
       fprintf(stderr, "  total %6.2f us\n", (double)(h[2 * c.n] - h[0]) / 100.0);
+      unsigned long long d[16 * 8];
+      if (hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbg), sizeof(d)) == hipSuccess)
+        for (int i = 0; i < c.n; ++i)
+          fprintf(stderr, "  tile of phase %2d: prefetch %5.2f  product %5.2f  lds %5.2f  update %5.2f  bias %5.2f\n", i,
+                  (double)(d[i * 8 + 1] - d[i * 8]) / 100.0, (double)(d[i * 8 + 2] - d[i * 8 + 1]) / 100.0,
+                  (double)(d[i * 8 + 3] - d[i * 8 + 2]) / 100.0, (double)(d[i * 8 + 4] - d[i * 8 + 3]) / 100.0,
+                  (double)(d[i * 8 + 5] - d[i * 8 + 4]) / 100.0);
     }
   }
 #endif
