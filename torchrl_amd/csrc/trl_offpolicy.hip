@@ -630,17 +630,22 @@ struct ChainState {
   int max_wgs = 0;                  // resident-workgroup budget of the device: two per CU
 };
 std::mutex g_chain_mu;
-std::unordered_map<const void *, ChainState *> g_chains;
+std::unordered_map<uint64_t, ChainState *> g_chains;     // key: workspace address ^ (device << 56)
 int g_chain_on = 1;
 
 ChainState *chain_state(const char *fn, const void *ws) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    trl_set_error("%s: hipGetDevice failed", fn);
+    return nullptr;
+  }
+  const uint64_t key = (uint64_t)(uintptr_t)ws ^ ((uint64_t)dev << 56);
   std::lock_guard<std::mutex> lk(g_chain_mu);
-  auto it = g_chains.find(ws);
+  auto it = g_chains.find(key);
   if (it != g_chains.end()) return it->second;
   ChainState *c = new ChainState();
-  int dev = 0, cus = 0;
-  bool ok = hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+  bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
             hipMalloc((void **)&c->bar, 256 * sizeof(unsigned)) == hipSuccess &&
             hipMemset(c->bar, 0, 256 * sizeof(unsigned)) == hipSuccess &&
             hipHostMalloc((void **)&c->tables, sizeof(PhaseArgs) * CHAIN_SLOTS * MAX_PHASES, hipHostMallocDefault) == hipSuccess;
@@ -655,7 +660,7 @@ ChainState *chain_state(const char *fn, const void *ws) {
     return nullptr;
   }
   c->max_wgs = 2 * cus;
-  g_chains[ws] = c;
+  g_chains[key] = c;
   return c;
 }
 
