@@ -1676,8 +1676,9 @@ struct InferArgs {
   float *value, *mean, *logp;
 };
 
+// (amdgpu_waves_per_eu(2): a register budget of 256, so that the MFMA results are taken in VGPRs -- see k_ac_learn_wide)
 template <int D, int KB0, int NO, bool XP>     // (hidden layers of at most 64 units; a wider one is k_ac_infer_wide's)
-__global__ __launch_bounds__(256) void k_ac_infer(InferArgs P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ac_infer(InferArgs P) {
   constexpr int HB = 1;
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;

@@ -968,9 +968,15 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
     add_dw(ph, B, g_material(W.dz2, A), A, W.a_h1, Ha1, nullptr, 0, a_off(ac->w[2]), a_off(ac->b[2]), 0);
     ch.add(ph);
   }
-  // One launch for the whole chain, or one per phase.  The step counts of a captured graph live on the device and
-  // its capture must not meet the chain's host-side event wait, so graph mode keeps the launches.
-  if (g_chain_on && !actor_opt->dev_state) {
+  // One launch for the whole chain, or one per phase.  A stream capture must not meet the chain's host-side event
+  // wait (and a replayed graph would re-read a table slot the host has since rewritten), so a capturing stream and
+  // graph mode (step counts on the device) keep the launches.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    cap = hipStreamCaptureStatusNone;
+  }
+  if (g_chain_on && !actor_opt->dev_state && cap == hipStreamCaptureStatusNone) {
     if ((rc = run_chain(ch, ws, st, fn))) return rc;
   } else if ((rc = run_launches(ch, st, fn))) {
     return rc;
