@@ -29,6 +29,11 @@
 //   * bias gradients and last-layer weight gradients are per-lane partial sums over the strips,
 //     reduced across lanes once, at the end.
 //
+// Three kernels share this plan: k_ac_learn (four waves, any fan-in up to 64), k_ac_learn_pair (two hidden layers over a
+// fan-in <= 4 at large batches: the two waves of a SIMD split the step by role) and k_ac_learn_wide (ONE hidden layer
+// of up to 256 units over a fan-in <= 4: layer 0 computed once per accumulator layout, nothing through LDS tiles);
+// k_ac_infer / k_ac_infer_wide are their forwards alone, bit for bit.
+//
 // Arithmetic is exact f32 (v_mfma_f32_32x32x2_f32 = k-ordered fma chain); the loss arithmetic
 // is the one of k_ppo_loss (trl_loss.hip), op for op.  Sums over k and over the batch are
 // taken in a different (fixed) order than torch's GEMMs, like any other GEMM kernel.
@@ -302,21 +307,21 @@ __device__ __forceinline__ void bwd_dx1(f32x16 (&t)[2], const f32x16 (&g)[2], co
 
 // weights of one network, zero-padded, into LDS, once per workgroup.  Loads first, stores after:
 // every load of a tile is in flight at once (a load -> store loop pays the L2 latency per iteration)
-template <int D, int LDW0, int NO, bool WITH_T, int HB = 1, int NT = 256>
+template <int D, int LDW0, int NO, bool WITH_T, int NT = 256>
 __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, float *sW1, float *sW1T, float *sWL,
                                               float *sB, int tid) {
   const int K0 = a.dims[0], H1 = a.dims[1], HL = a.dims[D - 1], NOr = a.dims[D];
   {
-    constexpr int N0 = (HB * 64 * LDW0 + NT - 1) / NT;
+    constexpr int N0 = (64 * LDW0 + NT - 1) / NT;
     float v[N0];
 #pragma unroll
     for (int i = 0; i < N0; ++i) {
-      const int e = tid + NT * i, n = e / LDW0, k = e % LDW0;      // n = q * 64 + local feature
-      v[i] = (n < H1 && k < K0 && e < HB * 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
+      const int e = tid + NT * i, n = e / LDW0, k = e % LDW0;
+      v[i] = (n < H1 && k < K0 && e < 64 * LDW0) ? a.w[0][n * K0 + k] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < N0; ++i)
-      if (tid + NT * i < HB * 64 * LDW0) sW0[tid + NT * i] = v[i];
+      if (tid + NT * i < 64 * LDW0) sW0[tid + NT * i] = v[i];
   }
   if (D == 3) {
     const int H2 = a.dims[2];
@@ -334,17 +339,17 @@ __device__ __forceinline__ void stage_weights(const NetArgs &a, float *sW0, floa
       if (WITH_T) sW1T[k * LDW + n] = v[i];
     }
   }
-  // last layer: block q of the hidden features at sWL + q * NO * 64, [n][64] each
-  for (int e = tid; e < HB * NO * 64; e += NT) {
-    const int q = e / (NO * 64), r = e - q * NO * 64, n = r >> 6, k = q * 64 + (r & 63);
+  // last layer: [n][64]
+  for (int e = tid; e < NO * 64; e += NT) {
+    const int n = e >> 6, k = e & 63;
     sWL[e] = (n < NOr && k < HL) ? a.w[D - 1][n * HL + k] : 0.f;
   }
-  // biases: b0 (HB * 64), b1 (64), bL (4)
-  for (int e = tid; e < HB * 64 + 64 + 4; e += NT) {
+  // biases: b0 (64), b1 (64), bL (4)
+  for (int e = tid; e < 64 + 64 + 4; e += NT) {
     float v = 0.f;
-    if (e < HB * 64) v = e < H1 ? a.b[0][e] : 0.f;
-    else if (e < HB * 64 + 64) v = (D == 3 && e - HB * 64 < a.dims[2]) ? a.b[1][e - HB * 64] : 0.f;
-    else v = e - HB * 64 - 64 < NOr ? a.b[D - 1][e - HB * 64 - 64] : 0.f;
+    if (e < 64) v = e < H1 ? a.b[0][e] : 0.f;
+    else if (e < 128) v = (D == 3 && e - 64 < a.dims[2]) ? a.b[1][e - 64] : 0.f;
+    else v = e - 128 < NOr ? a.b[D - 1][e - 128] : 0.f;
     sB[e] = v;
   }
 }
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
   const int A = P.A;
 
   STAMP(0);
-  stage_weights<D, LDW0, NO, true, 1, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
+  stage_weights<D, LDW0, NO, true, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
   float *sX = sT + wave * WTP;      // [32 KB0][LDT]  x^T of the strip
   float *sG = sX + XT;              // [64][LDT]      gradient w.r.t. a layer's pre-activation
   float *sH = sG + 64 * LDT;        // [64][LDT]      (D == 3) h1^T
@@ -1289,7 +1294,7 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   const int64_t B = P.B;
   const int A = P.A;
 
-  stage_weights<D, LDW0, NO, true, 1, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
+  stage_weights<D, LDW0, NO, true, NT>(a, sW0, sW1, sW1T, sWL, sB, tid);
   float *sXp = sT + pair * PT;          // [NXB][XT]   x^T of the strip, in rotation
   float *sG2 = sXp + NXB * XT;            // [64][LDT]   gradient w.r.t. layer 1's pre-activation
   float *sH1 = sG2 + 64 * LDT;          // [64][LDT]   h1^T
@@ -1679,13 +1684,12 @@ struct InferArgs {
 // (amdgpu_waves_per_eu(2): a register budget of 256, so that the MFMA results are taken in VGPRs -- see k_ac_learn_wide)
 template <int D, int KB0, int NO, bool XP>     // (hidden layers of at most 64 units; a wider one is k_ac_infer_wide's)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ac_infer(InferArgs P) {
-  constexpr int HB = 1;
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;
-  __shared__ __align__(16) float sW0[HB * 64 * LDW0];
+  __shared__ __align__(16) float sW0[64 * LDW0];
   __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];
-  __shared__ __align__(16) float sWL[HB * NO * 64];
-  __shared__ __align__(16) float sB[HB * 64 + 64 + 4];
+  __shared__ __align__(16) float sWL[NO * 64];
+  __shared__ __align__(16) float sB[64 + 64 + 4];
   __shared__ __align__(16) float sT[4 * XT];
   const int net = P.which[blockIdx.y];
   const NetArgs &a = P.net[net];
@@ -1693,7 +1697,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const int K0 = a.dims[0];
   const int64_t B = P.B;
   const int A = P.A;
-  stage_weights<D, LDW0, NO, false, HB>(a, sW0, sW1, nullptr, sWL, sB, tid);
+  stage_weights<D, LDW0, NO, false>(a, sW0, sW1, nullptr, sWL, sB, tid);
   float *sX = sT + wave * XT;
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;
   __syncthreads();
@@ -1776,20 +1780,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     wave_lds_fence();
     f32x16 h1[2], h2[2];
     float out[NO];
-    f32x2 pacc[NO];
-#pragma unroll
-    for (int n = 0; n < NO; ++n) pacc[n] = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int qb = 0; qb < HB; ++qb) {     // the hidden layer block by block: only the dot product's partial sum stays
-      fwd_layer0<LDW0>(h1, sX, sW0 + qb * 64 * LDW0, sB + qb * 64, ksteps0, half, r32);
-      if (D == 3) {
-        fwd_layer1(h2, h1, sW1, sB + HB * 64, half, r32);
-        fwd_last_acc<NO>(pacc, h2, sWL, half);
-      } else {
-        fwd_last_acc<NO>(pacc, h1, sWL + qb * NO * 64, half);
-      }
-    }
-    fwd_last_finish<NO>(out, pacc, sB + HB * 64 + 64);
+    fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+    if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+    fwd_last<NO>(out, D == 3 ? h2 : h1, sWL, sB + 128, half);
     if (valid && half == 0) {
       if (net == 0) {
         P.value[row] = out[0];
