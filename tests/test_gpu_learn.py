@@ -24,7 +24,10 @@ CASES = [(3, 1, (64, 64), 65536), (3, 1, (64, 64), 4097), (4, 2, (64, 64), 9000)
          (3, 1, (64, 64), 40001), (4, 2, (64, 64), 33000), (2, 2, (48, 33), 50000), (1, 1, (64, 20), 32768),
          # one hidden layer wider than 64 over <= 4 observations (ppo_controller.py:14 builds 256): hidden blocks
          (3, 1, (256,), 65536), (3, 1, (256,), 4097), (4, 1, (200,), 3000), (4, 2, (128,), 5000), (2, 2, (100,), 900),
-         (3, 1, (96,), 1000), (1, 1, (129,), 2048), (4, 2, (256,), 5000), (3, 2, (200,), 999)]
+         (3, 1, (96,), 1000), (1, 1, (129,), 2048), (4, 2, (256,), 5000), (3, 2, (200,), 999),
+         # ... and over 5 .. 9 observations (more k steps, more column groups of the layer-0 gradient)
+         (5, 1, (256,), 3000), (6, 2, (128,), 2500), (7, 1, (200,), 4097), (8, 2, (128,), 3000), (7, 2, (256,), 3000), (9, 1, (256,), 2000),
+         (9, 2, (100,), 1500), (8, 1, (128,), 40000)]
 
 
 def _batch(obs_size, A, B, seed):
@@ -107,14 +110,16 @@ def test_fused_learn_is_reproducible_and_rejects_bad_shapes():
   assert PPOController(3, 1, device=DEV, hidden=(128, 64))._fused is None              # too wide: general path
   assert PPOController(3, 3, device=DEV, hidden=(64, 64))._fused is None               # A > 2 with two hidden layers
   assert PPOController(3, 3, device=DEV, hidden=(256,))._fused is None                 # wide: two actions at most
-  assert PPOController(5, 1, device=DEV, hidden=(256,))._fused is None                 # wide needs a fan-in <= 4
+  assert PPOController(10, 1, device=DEV, hidden=(256,))._fused is None                # wide needs a fan-in <= 9
+  assert PPOController(8, 2, device=DEV, hidden=(256,))._fused is None                 # ... <= 7 with two actions above 128 wide
   assert PPOController(3, 1, device=DEV, hidden=(257,))._fused is None
 
 
 @pytest.mark.parametrize('obs_size,A,hidden,B', [(3, 1, (64, 64), 70001), (4, 2, (64, 64), 4096), (40, 2, (48, 33), 999),
                                                  (5, 4, (64,), 12345), (64, 1, (64, 64), 300),
                                                  (3, 1, (256,), 70001), (4, 2, (128,), 1234), (2, 1, (130,), 333),
-                                                 (4, 2, (256,), 4321)])
+                                                 (4, 2, (256,), 4321), (8, 2, (128,), 2000), (6, 2, (130,), 777),
+                                                 (9, 1, (256,), 5000)])
 def test_fused_forward_matches_torch(obs_size, A, hidden, B):
   """trl_ppo_forward_fused (value / mean / log-prob, outputs only) vs the torch modules."""
   torch.manual_seed(B)
@@ -136,7 +141,8 @@ def test_fused_forward_matches_torch(obs_size, A, hidden, B):
 
 @pytest.mark.parametrize('obs_size,A,hidden,B', [(3, 1, (64, 64), 40001), (3, 1, (64, 64), 5000), (4, 2, (64, 64), 33000),
                                                  (12, 1, (64, 48), 3000), (4, 1, (64,), 2000), (3, 1, (256,), 40001),
-                                                 (4, 2, (256,), 3000), (2, 1, (130,), 1000), (4, 2, (128,), 35000)])
+                                                 (4, 2, (256,), 3000), (2, 1, (130,), 1000), (4, 2, (128,), 35000),
+                                                 (8, 2, (128,), 3000), (7, 2, (256,), 2000), (9, 1, (100,), 1500)])
 def test_forward_kernel_and_learner_forward_are_the_same_bits(obs_size, A, hidden, B):
   """The forward-only kernel and the learner kernels evaluate a row to the same bit pattern (PPO's first-epoch ratio is
   exactly 1; A2C's detached advantage uses the learner's own V).  Observable without a debug output: with the forward
@@ -186,7 +192,8 @@ def test_compute_return_fused_equals_general_path(monkeypatch):
 
 @pytest.mark.parametrize('obs_size,A,hidden,B', [(4, 2, 64, 9001), (4, 2, (64, 64), 4096), (4, 2, (64, 64), 40000), (8, 4, 48, 5000),
                                                  (40, 3, 64, 700), (3, 1, (33, 20), 2048), (4, 2, 128, 9001),
-                                                 (4, 2, 100, 700), (4, 2, 256, 9001), (4, 2, 180, 1500)])
+                                                 (4, 2, 100, 700), (4, 2, 256, 9001), (4, 2, 180, 1500),
+                                                 (8, 2, 128, 3000), (6, 2, 256, 2000), (9, 2, 100, 1000)])
 def test_fused_a2c_learn_matches_oracle(obs_size, A, hidden, B):
   """trl_a2c_learn_fused vs the oracle's torch-CPU A2CController.learn (a2c_controller.py:47-69):
   softmax actor + Categorical loss, losses to 1e-6 relative, gradients, weights after Adam."""

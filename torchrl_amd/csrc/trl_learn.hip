@@ -907,17 +907,22 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 // factor of the whole of feature f's layer-0 gradient and is applied once, at the end.
 // (amdgpu_waves_per_eu(2): with a budget of 256 registers the compiler takes the MFMA results in VGPRs; with the 512
 // of one wave per SIMD it puts them in AGPRs and pays a v_accvgpr_read per element ahead of every VALU use)
-template <int NO, int HB, bool K4>
+// KS = k steps of two of the layer-0 products: the fan-in and the bias column, K0 + 1 <= 2 KS (a compile-time count: a
+// branch around an MFMA costs copies of its 16 accumulators).  NG = groups of four columns of the layer-0 gradient (one
+// 4x4x1 product per row and group): the K0 columns of dW0 and, where a group has room, the ones column = db0.
+// BV: a fan-in of 4 or 8 fills its groups, and db0 is summed on the VALU instead of opening a group for one column.
+//   fan-in <= 3: KS 2, NG 1;  4: 3, 1, BV;  5: 3, 2;  6-7: 4, 2;  8: 5, 2, BV;  9: 5, 3   (wide_class below)
+template <int NO, int HB, int KS, int NG, bool BV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ac_learn_wide(LearnArgs P) {
   constexpr int NW = 4, NT = 64 * NW, F = HB * 64;
-  constexpr int XR = 6;                               // rows of the x tile: <= 4 inputs, the ones row, zeros to an even count
+  constexpr int XR = 4 * NG > 2 * KS ? 4 * NG : 2 * KS;   // rows of the x tile: the inputs, the ones row, zeros
   constexpr int XT = XR * LDT + 4;                    // (+ a dummy slot for idle prefetch lanes)
   constexpr int WT = XT + NO * LDT;                   // per-wave scratch: x^T tile, output-gradient rows
-  constexpr int NS = NO + 5;                          // per-feature sums: NO rows of dWL, 4 columns of dW0, db0 (fan-in 4)
+  constexpr int NS = NO + 4 * NG + 1;                 // per-feature sums: NO rows of dWL, 4 NG columns of [dW0 | db0], db0 (BV)
   constexpr int OFF_WL = 0, OFF_BL = OFF_WL + HB * NO * 64, OFF_S = OFF_BL + 4, OFF_T = OFF_S + NW * 16,
                 OFF_R = OFF_T + NW * WT;
   static_assert(XT % 4 == 0 && WT % 4 == 0 && OFF_T % 4 == 0, "16 B rows");
-  __shared__ __align__(16) float smem[OFF_R + 2 * NW * NS * F];
+  __shared__ __align__(16) float smem[OFF_R + NW * NS * F];
   float *const sWL = smem + OFF_WL, *const sBL = smem + OFF_BL, *const scal = smem + OFF_S, *const sR = smem + OFF_R;
 
   const int net = blockIdx.y;
@@ -940,8 +945,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   if (lane < 32) sX[K0 * LDT + lane] = 1.f;
   // layer 0's weight operand, the same register for both products: W0'[f][k = 2 s + half] of feature
   // f = 64 q + 32 nb + (lane & 31); and the lane's own last-layer weights
-  constexpr int KS = K4 ? 3 : 2;            // k steps of two: the inputs and the bias column (a compile-time count:
-                                            // a branch around an MFMA costs copies of its 16 accumulators)
   float wop[HB][2][KS];
 #pragma unroll
   for (int q = 0; q < HB; ++q)
@@ -962,8 +965,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
   // ---- per-wave persistent state: everything per FEATURE (lane & 31 of block q, half nb), summed over the rows
   // 8 j + 4 half + i of every strip
-  f32x2 dwl[HB][2][NO], vdb0[HB][2];     // (even rows, odd rows)
-  f32x4 dw0m[HB][2];       // element i of lane 4 b + k: dW0[feature 4 (b & 7) + i][k], rows of half b >> 3
+  f32x2 dwl[HB][2][NO], vdb0[HB][2];    // (even rows, odd rows)
+  f32x4 dw0m[HB][2][NG];   // element i of lane 4 b + j, group g: [dW0 | db0][feature 4 (b & 7) + i][4 g + j], rows of half b >> 3
 #pragma unroll
   for (int q = 0; q < HB; ++q)
 #pragma unroll
@@ -971,9 +974,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
       for (int n = 0; n < NO; ++n) dwl[q][nb][n] = f32x2{0.f, 0.f};
       vdb0[q][nb] = f32x2{0.f, 0.f};
-      dw0m[q][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < NG; ++g) dw0m[q][nb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  // K4: a fan-in of 4 leaves no room for the ones row among the four B lanes, and db0 is summed on the VALU
   float dbL[NO], s_main = 0.f, s_ent = 0.f, s_dls[NO], den[NO], var[NO], logsig[NO];
 #pragma unroll
   for (int n = 0; n < NO; ++n) {
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const float gmin = uni(-(1.0f / (float)(B * A)));   // d loss / d min(surr1, surr2) element
 
   // ---- a strip's inputs are fetched one strip ahead, into registers, branch-free (as in k_ac_learn)
-  constexpr int XPF = 2;
+  constexpr int XPF = KS;      // 32 K0 <= 64 KS elements
   const int nelem = 32 * K0;
   int xoff[XPF];
 #pragma unroll
@@ -1095,13 +1098,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     wave_lds_fence();
     // rows 8 j + 4 half + i of the strip, register 4 j + i: the output gradients (broadcast reads) and, for the
-    // 4x4 products, input (lane & 3) of those rows
-    float4 go[NO][4], xq[4];
+    // 4x4 products of column group g, column 4 g + (lane & 3) of x' at those rows
+    // (HOLDX: held for the whole strip; with many blocks and groups the registers go to the accumulators instead and
+    // the x' quads are read again per 32 features, under the recompute's MFMAs)
+    constexpr bool HOLDX = HB * NG <= 4;
+    float4 go[NO][4], xq[NG][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int n = 0; n < NO; ++n) go[n][j] = ld4(sGo + n * LDT + 8 * j + 4 * half);
-      xq[j] = ld4(sX + (lane & 3) * LDT + 8 * j + 4 * half);
+      if (HOLDX) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xq[g][j] = ld4(sX + (4 * g + (lane & 3)) * LDT + 8 * j + 4 * half);
+      }
     }
     PH(1);
 
@@ -1115,6 +1124,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int r = 0; r < 16; ++r) pre[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) pre = MFMA(xop[s], wop[q][nb][s], pre);
+        if (!HOLDX) {
+          const float *xb = sX + wl_off + (lane & 3) * LDT + 4 * half;      // (wl_off = 0: keeps these reads in the loop)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xq[g][j] = ld4(xb + 4 * g * LDT + 8 * j);
+        }
         float wlb[NO];       // the feature's own last-layer weights (read under the MFMAs)
 #pragma unroll
         for (int n = 0; n < NO; ++n) wlb[n] = NO == 1 ? 0.f : sWL[wl_off + (q * NO + n) * 64 + nb * 32 + r32];
@@ -1143,12 +1159,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int n = 0; n < NO; ++n) dwl[q][nb][n] = __builtin_elementwise_fma(hr, gn[n], dwl[q][nb][n]);
             av = f32x2{x.x > 0.f ? t.x : 0.f, x.y > 0.f ? t.y : 0.f};
           }
-          const float4 x4 = xq[r >> 2];
-          dw0m[q][nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, (r & 2) ? x4.z : x4.x, dw0m[q][nb], 0, 0, 0);
-          dw0m[q][nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, (r & 2) ? x4.w : x4.y, dw0m[q][nb], 0, 0, 0);
-          if (K4) sdb += av;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const float4 x4 = xq[g][r >> 2];
+            dw0m[q][nb][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, (r & 2) ? x4.z : x4.x, dw0m[q][nb][g], 0, 0, 0);
+            dw0m[q][nb][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, (r & 2) ? x4.w : x4.y, dw0m[q][nb][g], 0, 0, 0);
+          }
+          if (BV) sdb += av;
         }
-        if (K4) vdb0[q][nb] += sdb;
+        if (BV) vdb0[q][nb] += sdb;
         __builtin_amdgcn_sched_barrier(0);
       }
     wave_lds_fence();     // the next strip overwrites sX and sGo
@@ -1171,25 +1190,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
     for (int j = 0; j < 2 + 2 * NO; ++j) scal[wave * 16 + j] = sc[j];
   }
-  // per-feature sums: one copy per (wave, lane half), added in that order
-  float *mine = sR + (wave * 2 + half) * NS * F;
+  // per-feature sums: the two lane halves (the same features over different rows) are added first, then one copy per
+  // wave, in wave order
+  float *mine = sR + wave * NS * F;
 #pragma unroll
   for (int q = 0; q < HB; ++q)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int fb = q * 64 + nb * 32;
 #pragma unroll
-      for (int n = 0; n < NO; ++n) mine[n * F + fb + r32] = dwl[q][nb][n].x + dwl[q][nb][n].y;
+      for (int n = 0; n < NO; ++n) {
+        const float v = dwl[q][nb][n].x + dwl[q][nb][n].y;
+        const float t = v + __shfl_xor(v, 32, 64);
+        if (half == 0) mine[n * F + fb + r32] = t;
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mine[(NO + (lane & 3)) * F + fb + 4 * (r32 >> 2) + i] = dw0m[q][nb][i];
-      mine[(NO + 4) * F + fb + r32] = vdb0[q][nb].x + vdb0[q][nb].y;
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = dw0m[q][nb][g][i];
+          const float t = v + __shfl_xor(v, 32, 64);
+          if (half == 0) mine[(NO + 4 * g + (lane & 3)) * F + fb + 4 * (r32 >> 2) + i] = t;
+        }
+      {
+        const float v = vdb0[q][nb].x + vdb0[q][nb].y;
+        const float t = v + __shfl_xor(v, 32, 64);
+        if (half == 0) mine[(NO + 4 * NG) * F + fb + r32] = t;
+      }
     }
   __syncthreads();
   for (int e = tid; e < NS * F; e += NT) {
     const int sl = e / F, f = e - sl * F;
     float v = sR[e];
 #pragma unroll
-    for (int c = 1; c < 2 * NW; ++c) v += sR[c * NS * F + e];
+    for (int c = 1; c < NW; ++c) v += sR[c * NS * F + e];
     if (f >= H1) continue;
     if (sl < NO) {
       if (sl < NOr) part[a.poff[1] + sl * H1 + f] = v;
@@ -1197,7 +1231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       const int k = sl - NO;
       if (NO == 1) v *= sWL[(f >> 6) * 64 + (f & 63)];
       if (k < K0) part[a.poff[0] + f * K0 + k] = v;
-      else if (k == K0) part[a.poff[0] + H1 * K0 + f] = v;      // the ones column, or (fan-in 4) the VALU sum
+      else if (BV ? k == 4 * NG : k == K0) part[a.poff[0] + H1 * K0 + f] = v;      // db0: the VALU sum, or the ones column
     }
   }
   if (tid < 2 + 2 * NO) {
@@ -1806,10 +1840,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 // same k order ([W0 | b0] [x | 1]^T from C = 0) and the same packed dot product, so a value or log-prob computed here
 // is the bit pattern the learner kernel computes for that row (PPO's first-epoch ratio is exactly 1; A2C's detached
 // advantage uses the learner's own V).  Small LDS footprint and <= 128 registers: several workgroups per CU.
-template <int NO, int HB, bool K4>
+template <int NO, int HB, int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ac_infer_wide(InferArgs P) {
   constexpr int NW = 4, NT = 64 * NW;
-  constexpr int XR = 6, XT = XR * LDT + 4;
+  constexpr int XR = 2 * KS, XT = XR * LDT + 4;
   __shared__ __align__(16) float sWL[HB * NO * 64];
   __shared__ __align__(16) float sBL[4];
   __shared__ __align__(16) float sT[NW * XT];
@@ -1828,7 +1862,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   float *sX = sT + wave * XT;
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;
   if (lane < 32) sX[K0 * LDT + lane] = 1.f;
-  constexpr int KS = K4 ? 3 : 2;
   float wop[HB][2][KS];
 #pragma unroll
   for (int q = 0; q < HB; ++q)
@@ -1856,7 +1889,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       logsig[n] = logf(sigma);
     }
   }
-  constexpr int XPF = 2;
+  constexpr int XPF = KS;
   const int nelem = 32 * K0;
   int xoff[XPF];
 #pragma unroll
@@ -2040,14 +2073,18 @@ __global__ __launch_bounds__(256) void k_learn_reduce(ReduceArgs R, int param_bl
   }
 }
 
+constexpr int WIDE_FANIN_MAX = 9;      // k_ac_learn_wide / k_ac_infer_wide: K0 + 1 <= 2 KS, KS <= 5
+inline int wide_ks(int K0) { return K0 <= 3 ? 2 : (K0 <= 5 ? 3 : (K0 <= 7 ? 4 : 5)); }
+inline int wide_class(int K0) { return K0 <= 3 ? 0 : (K0 == 4 ? 1 : (K0 == 5 ? 2 : (K0 <= 7 ? 3 : (K0 == 8 ? 4 : 5)))); }
+
 int fill_net(const char *fn, const trl_mlp_desc *d, int out_max, NetArgs *a, int hidden_max = 64) {
   TRL_REQUIRE(d != nullptr, "%s: null network description", fn);
   TRL_REQUIRE(d->depth == 2 || d->depth == 3, "%s: depth %d not in {2, 3}", fn, d->depth);
   a->depth = d->depth;
   int off = 0;
   for (int l = 0; l <= d->depth; ++l) {
-    // one hidden layer over a fan-in of at most 4: up to 256 units, walked as 64-wide blocks (HB)
-    const int wide = (d->depth == 2 && l == 1 && hidden_max > 64 && d->dims[0] <= 4) ? hidden_max : 64;
+    // one hidden layer over a fan-in of at most WIDE_FANIN_MAX: up to 256 units, walked as 64-wide blocks (HB)
+    const int wide = (d->depth == 2 && l == 1 && hidden_max > 64 && d->dims[0] <= WIDE_FANIN_MAX) ? hidden_max : 64;
     const int lim = l == d->depth ? out_max : wide;
     TRL_REQUIRE(d->dims[l] >= 1 && d->dims[l] <= lim, "%s: dims[%d]=%d must be in [1, %d]", fn, l, d->dims[l], lim);
     a->dims[l] = d->dims[l];
@@ -2179,14 +2216,25 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
     if (NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair<1>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_ac_learn_pair<2>), grid, block, 0, st, P);
   } else if (D == 2 && (hmax > 64 || (onewide && critic->dims[0] <= 4 && NOv <= 2))) {
-    // one hidden layer over a fan-in <= 4 (fill_net has checked the fan-in of the wide ones): 1, 2 or 4 blocks of 64
+    // one hidden layer: 65 .. 256 wide over a fan-in <= WIDE_FANIN_MAX (fill_net has checked it), or <= 64 wide over a
+    // fan-in <= 4 -- 1, 2 or 4 blocks of 64
     TRL_REQUIRE(NOv <= 2, "%s: a hidden layer of %d units takes an action size of at most 2 (got %d)", fn, hmax, A);
-#define TRL_WIDE_CASE(no, hb)                                                                     \
-  if (NOv == no && (hmax <= 64 ? 1 : (hmax <= 128 ? 2 : 4)) == hb) {                               \
-    if (critic->dims[0] == 4) hipLaunchKernelGGL((k_ac_learn_wide<no, hb, true>), grid, block, 0, st, P); \
-    else hipLaunchKernelGGL((k_ac_learn_wide<no, hb, false>), grid, block, 0, st, P);             \
-  }
-    TRL_WIDE_CASE(1, 1) TRL_WIDE_CASE(2, 1) TRL_WIDE_CASE(1, 2) TRL_WIDE_CASE(2, 2) TRL_WIDE_CASE(1, 4) TRL_WIDE_CASE(2, 4)
+    const int HBv = hmax <= 64 ? 1 : (hmax <= 128 ? 2 : 4), cls = wide_class(critic->dims[0]);
+    // (four blocks, two outputs and 8 - 9 inputs: the accumulators alone leave no registers -- 184 / 328 B of scratch)
+    TRL_REQUIRE(!(HBv == 4 && NOv == 2 && cls >= 4),
+                "%s: a hidden layer of %d units with two actions takes at most 7 observations (got %d)", fn, hmax,
+                critic->dims[0]);
+#define TRL_WIDE_CASE(no, hb, c, ks, ng, bv) \
+  if (NOv == no && HBv == hb && cls == c) hipLaunchKernelGGL((k_ac_learn_wide<no, hb, ks, ng, bv>), grid, block, 0, st, P);
+#define TRL_WIDE_CASES(no, hb)                                                                  \
+  TRL_WIDE_CASE(no, hb, 0, 2, 1, false) TRL_WIDE_CASE(no, hb, 1, 3, 1, true) TRL_WIDE_CASE(no, hb, 2, 3, 2, false) \
+  TRL_WIDE_CASE(no, hb, 3, 4, 2, false) TRL_WIDE_CASE(no, hb, 4, 5, 2, true) TRL_WIDE_CASE(no, hb, 5, 5, 3, false)
+    TRL_WIDE_CASE(1, 1, 0, 2, 1, false) TRL_WIDE_CASE(1, 1, 1, 3, 1, true)
+    TRL_WIDE_CASE(2, 1, 0, 2, 1, false) TRL_WIDE_CASE(2, 1, 1, 3, 1, true)
+    TRL_WIDE_CASES(1, 2) TRL_WIDE_CASES(1, 4) TRL_WIDE_CASES(2, 2)
+    TRL_WIDE_CASE(2, 4, 0, 2, 1, false) TRL_WIDE_CASE(2, 4, 1, 3, 1, true) TRL_WIDE_CASE(2, 4, 2, 3, 2, false)
+    TRL_WIDE_CASE(2, 4, 3, 4, 2, false)
+#undef TRL_WIDE_CASES
 #undef TRL_WIDE_CASE
   } else {
   TRL_LEARN_CASE(2, 1, 1) TRL_LEARN_CASE(2, 1, 2) TRL_LEARN_CASE(2, 1, 4)
@@ -2255,7 +2303,7 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
   P.value = value; P.mean = mean; P.logp = logp;
   int hmax = 0;
   for (int i = 0; i < ny; ++i) hmax = P.net[P.which[i]].dims[1] > hmax ? P.net[P.which[i]].dims[1] : hmax;
-  // one hidden layer over a fan-in <= 4: the learner's own forward (k_ac_learn_wide: any width up to 256; at most 64 wide
+  // one hidden layer the learner takes with k_ac_learn_wide: its own forward (65 .. 256 wide; at most 64 wide
   // only when the learner takes that kernel too, i.e. at most two actions -- A is read for this even when only the value
   // is asked for)
   const bool wide = D == 2 && (hmax > 64 || (K0 <= 4 && (A < 1 || A <= 2)));
@@ -2271,13 +2319,15 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
     else hipLaunchKernelGGL((k_ac_infer<d, kb, no, false>), grid, block, 0, st, P);               \
   }
   if (wide) {     // wide single hidden layer (fill_net has checked fan-in <= 4): blocks of 64
-#define TRL_WIDE_CASE(no, hb)                                                                     \
-  if (NOv == no && (hmax <= 64 ? 1 : (hmax <= 128 ? 2 : 4)) == hb) {                               \
-    if (K0 == 4) hipLaunchKernelGGL((k_ac_infer_wide<no, hb, true>), grid, block, 0, st, P);       \
-    else hipLaunchKernelGGL((k_ac_infer_wide<no, hb, false>), grid, block, 0, st, P);             \
-  }
-    TRL_WIDE_CASE(1, 1) TRL_WIDE_CASE(2, 1)
-    TRL_WIDE_CASE(1, 2) TRL_WIDE_CASE(2, 2) TRL_WIDE_CASE(4, 2) TRL_WIDE_CASE(1, 4) TRL_WIDE_CASE(2, 4) TRL_WIDE_CASE(4, 4)
+    const int HBv = hmax <= 64 ? 1 : (hmax <= 128 ? 2 : 4), KSv = wide_ks(K0);
+#define TRL_WIDE_CASE(no, hb, ks) \
+  if (NOv == no && HBv == hb && KSv == ks) hipLaunchKernelGGL((k_ac_infer_wide<no, hb, ks>), grid, block, 0, st, P);
+#define TRL_WIDE_CASES(no)                                                                              \
+  TRL_WIDE_CASE(no, 2, 2) TRL_WIDE_CASE(no, 2, 3) TRL_WIDE_CASE(no, 2, 4) TRL_WIDE_CASE(no, 2, 5)         \
+  TRL_WIDE_CASE(no, 4, 2) TRL_WIDE_CASE(no, 4, 3) TRL_WIDE_CASE(no, 4, 4) TRL_WIDE_CASE(no, 4, 5)
+    TRL_WIDE_CASE(1, 1, 2) TRL_WIDE_CASE(1, 1, 3) TRL_WIDE_CASE(2, 1, 2) TRL_WIDE_CASE(2, 1, 3)
+    TRL_WIDE_CASES(1) TRL_WIDE_CASES(2) TRL_WIDE_CASES(4)
+#undef TRL_WIDE_CASES
 #undef TRL_WIDE_CASE
   } else {
   TRL_INFER_CASE(2, 1, 1) TRL_INFER_CASE(2, 1, 2) TRL_INFER_CASE(2, 1, 4)

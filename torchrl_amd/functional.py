@@ -680,7 +680,7 @@ def mlp64(x, weights, biases, direct_grads=False):
 # ------------------------------------------------------------------------------ fused PPO learner step
 class FusedPpoLearn:
   """forward + PPO loss + backward of an ActorCriticNet whose stacks are at most 64 wide (one hidden
-  layer over <= 4 observations: up to 256 wide), as one
+  layer over <= 9 observations: up to 256 wide), as one
   launch (+ a small reduce): csrc/trl_learn.hip, C ABI trl_ppo_learn_fused.
 
   Built once per controller from the stacks' Linear modules (whose parameters and .grad views live
@@ -706,11 +706,11 @@ class FusedPpoLearn:
       return False
     if critic_lin[0].in_features != actor_lin[0].in_features:
       return False
-    # one hidden layer over a fan-in of at most 4 and at most two actions may be up to 256 wide (the
-    # reference's own shape, ppo_controller.py:14 / a2c_controller.py: k_ac_learn's HB blocks)
+    # one hidden layer over a fan-in of at most 9 and at most two actions may be up to 256 wide (the
+    # reference's own shape, ppo_controller.py:14 / a2c_controller.py: k_ac_learn_wide)
     wide = 64
-    if len(critic_lin) == 2 and critic_lin[0].in_features <= 4 and A <= 2:
-      wide = 256
+    if len(critic_lin) == 2 and critic_lin[0].in_features <= 9 and A <= 2:
+      wide = 128 if (A == 2 and critic_lin[0].in_features > 7) else 256     # (register budget of the widest variant)
     for lin in (critic_lin, actor_lin):
       for i, m in enumerate(lin):
         if m.bias is None or m.in_features > wide or (i + 1 < len(lin) and m.out_features > wide):
