@@ -320,8 +320,8 @@ int trl_mlp_bwd_group(const trl_mlp_desc *nets, int32_t G, const float *const *x
  * small fixed-order reduction: a wavefront carries 32 samples from the observation to the
  * parameter-gradient partials with the activations in registers (csrc/trl_learn.hip).
  *   critic, actor: depth 2 or 3 (one or two hidden layers, ReLU between), same depth and fan-in;
- *   a single hidden layer over a fan-in of at most 4 may be up to 256 wide with A <= 2 (walked as
- *   64-wide blocks inside the wave), every other width at most 64;
+ *   a single hidden layer over a fan-in of at most 9 may be up to 256 wide with A <= 2 (walked as
+ *   64-wide blocks inside the wave; with A = 2 and a fan-in of 8 or 9: up to 128 wide), every other width at most 64;
  *   critic fan-out 1, actor fan-out A (1 <= A <= 4);  log_std [A];  obs [B, fan-in];
  *   action, old_logp [B, A];  returns, adv [B].
  *   losses_out[0..3] = actor, critic, entropy, actor + alpha * critic - beta * entropy.
@@ -370,7 +370,7 @@ int trl_a2c_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
  * mean / log-prob pass of PPOController.compute_return (ppo_controller.py:34, 48) and act().
  *   value [B] (needs critic), mean [B, A], logp [B, A] = Normal(mean, exp(log_std)).log_prob(action)
  *   per dimension (need actor; logp also action [B, A] and log_std [A]); any output may be NULL.
- * Depth 2 or 3, widths <= 64, 1 <= A <= 4; one hidden layer (depth 2) over at most 4 observations
+ * Depth 2 or 3, widths <= 64, 1 <= A <= 4; one hidden layer (depth 2) over at most 9 observations
  * may be up to 256 wide (the width ppo_controller.py:14 builds).
  * A row's value / mean / log-prob is the bit pattern trl_ppo_learn_fused / trl_a2c_learn_fused compute for
  * it on the same networks (a first-epoch PPO ratio is exactly 1).  Pass the actor's action size in A even
