@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // One WIDE hidden layer (65 .. 256 units: the reference's own ActorCriticNet / A2CNet width, ppo_controller.py:14)
-// over a fan-in of at most 4.  That shape has no square product: per 64-feature block only layer 0 (K <= 4), the
+// over a fan-in of at most 9.  That shape has no square product: per 64-feature block only layer 0 (K <= 9), the
 // last layer's dot product and their transposes, so the step is VALU- and LDS-bound, not MFMA-bound, and what counts
 // is instructions per strip.  k_ac_learn's plan (activations held from forward to backward, every gradient tile
 // transposed through LDS) needs 128 + 128 registers for 4 blocks and ran out of them.  Here nothing is held and
@@ -899,9 +899,9 @@ __global__ __launch_bounds__(256) void k_ac_learn(LearnArgs P) {
 //   backward: H   = X' W0'^T  (the SAME two operand registers, swapped): lane = feature, register = sample.  The
 //             ReLU mask, g = (WL^T gout) * mask, dWL[f] += sum_row h g_out, and the 4x4x1 MFMA outer products
 //             dW0[f][k] += g[f][row] x[k][row] all reduce over REGISTERS of the lane that owns feature f: one
-//             accumulator per feature, no LDS tile.  The recompute is 2-3 MFMAs per 32 features.
-// W0' = [W0 | b0] and X' = [x | 1] (the bias is one more k column, so the products start from C = 0, and for a fan-in
-// < 4 column K0 of the dW0 products is the bias gradient; a fan-in of 4 sums it beside them).  W0's operands and the
+//             accumulator per feature, no LDS tile.  The recompute is 2-5 MFMAs per 32 features.
+// W0' = [W0 | b0] and X' = [x | 1] (the bias is one more k column, so the products start from C = 0, and column K0 of
+// the dW0 products is the bias gradient wherever a group of four columns has room for it).  W0's operands and the
 // lane's own last-layer weights are loop-invariant and live in registers; per strip the wave reads only the x tile,
 // the last layer's rows (forward) and the strip's output gradients from LDS.  One output (NO == 1): WL[f] is a
 // factor of the whole of feature f's layer-0 gradient and is applied once, at the end.
