@@ -668,11 +668,19 @@ ChainState *chain_state(const char *fn, const void *ws) {
 struct Chain {
   PhaseArgs ph[MAX_PHASES];
   int n = 0;
-  void add(const Phase &p) { ph[n] = p.a; ph[n].wgs = p.wgs; ++n; }
-  void add_losses(const LossArgs &L) { memset(&ph[n], 0, sizeof(PhaseArgs)); ph[n].L = L; ph[n].wgs = 0; ++n; }
+  bool full = false;      // (more phases than the table holds: refused by the runners)
+  void add(const Phase &p) {
+    if (n >= MAX_PHASES) { full = true; return; }
+    ph[n] = p.a; ph[n].wgs = p.wgs; ++n;
+  }
+  void add_losses(const LossArgs &L) {
+    if (n >= MAX_PHASES) { full = true; return; }
+    memset(&ph[n], 0, sizeof(PhaseArgs)); ph[n].L = L; ph[n].wgs = 0; ++n;
+  }
 };
 
 int run_launches(const Chain &c, hipStream_t st, const char *what) {
+  TRL_REQUIRE(!c.full, "%s: internal: more than %d phases", what, MAX_PHASES);
   for (int i = 0; i < c.n; ++i) {
     if (c.ph[i].wgs == 0) hipLaunchKernelGGL(k_ddpg_losses, dim3(1), dim3(256), 0, st, c.ph[i].L);
     else hipLaunchKernelGGL(k_phase, dim3(c.ph[i].wgs), dim3(256), 0, st, c.ph[i]);
@@ -682,6 +690,7 @@ int run_launches(const Chain &c, hipStream_t st, const char *what) {
 }
 
 int run_chain(const Chain &c, const void *ws, hipStream_t st, const char *what) {
+  TRL_REQUIRE(!c.full, "%s: internal: more than %d phases", what, MAX_PHASES);
   ChainState *cs = chain_state(what, ws);
   if (!cs) return TRL_EHIP;
   const int slot = (int)(cs->n++ % CHAIN_SLOTS);
