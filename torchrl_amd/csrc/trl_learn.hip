@@ -1576,12 +1576,7 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
       pair_wait(pub + 0, it + 1);
       TRACE(1);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gB[kb][r] = sG2[(kb * 32 + feat(r, half)) * LDT + r32];
-#pragma unroll
       for (int j = 0; j < 4; ++j) { G0[j] = ld4(ga + 8 * j); G1[j] = ld4(ga + 32 * LDT + 8 * j); }
-      pair_post(pub + 2, it + 1, lane);         // (waits for the reads above)
       // Order of the two MFMA streams.  A wave that streams MFMAs keeps the SIMD's matrix pipe, and its partner's
       // VALU work crawls meanwhile (26-28 cycles per instruction).  Left to the race, this wave's stream goes first
       // and A's forward of the NEXT strip after it; A's loss and last layer then run with the pipe idle.  Held back
@@ -1589,8 +1584,28 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
       if (hold) pair_wait(pub + 4, it + 2);
       TRACE(2);
       MATRIX_PHASE();
+      // The 8 row reads are all the first product needs: its MFMAs start behind them, and the 32 reads of the
+      // accumulator-layout copy (the second product's operand) go out two behind each of the first 16 MFMAs -- LDS
+      // traffic runs at full rate beside an MFMA stream -- instead of ahead of the first one.
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i) {
+        accW1[0][0] = MFMA(f4(G0[0], i), f4(X0[0], i), accW1[0][0]);
+        accW1[0][1] = MFMA(f4(G0[0], i), f4(X1[0], i), accW1[0][1]);
+        accW1[1][0] = MFMA(f4(G1[0], i), f4(X0[0], i), accW1[1][0]);
+        accW1[1][1] = MFMA(f4(G1[0], i), f4(X1[0], i), accW1[1][1]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gB[kb][r] = sG2[(kb * 32 + feat(r, half)) * LDT + r32];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // two LDS reads
+      }
+      pair_post(pub + 2, it + 1, lane);         // (LDS keeps issue order: the store follows the reads above)
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           accW1[0][0] = MFMA(f4(G0[j], i), f4(X0[j], i), accW1[0][0]);
