@@ -629,7 +629,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
                  'gemm_selection': 'blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)',
                  'learn_step': 'hip-graph replay' if args.use_graph else
                  (('eager, whole step in %d launches (csrc/trl_offpolicy.hip)' % (9 if not args.f32_frames else 6)) if atari
-                  else 'eager, the 11 phases of the step in ONE launch (k_chain, csrc/trl_offpolicy.hip)'
+                  else 'eager, the 10 phases of the step in ONE launch (k_chain, csrc/trl_offpolicy.hip)'
                   if getattr(ctl, '_fused', None) is not None else 'eager')},
       'roofline': roof,
   }

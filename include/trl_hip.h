@@ -380,7 +380,8 @@ int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor,
                           float *logp, void *stream);
 
 /* ------------------------------------------------------------------ fused off-policy learner steps (a-2 + a-4)
- * DDPGController.learn (ddpg_controller.py:101-128) as 11 launches (csrc/trl_offpolicy.hip): the five
+ * DDPGController.learn (ddpg_controller.py:101-128) as 10 phases of one tile kernel (csrc/trl_offpolicy.hip;
+ * one launch, or one per phase: trl_offpolicy_set_chain): the five
  * forward passes (actor(obs), critic(obs, actor(obs)), critic(obs, action), target_critic(next_obs,
  * target_actor(next_obs)); models.py:27-81), y = reward + (1 - done) * gamma * target_q, the two
  * losses, the backward of -mean Q through the critic into the actor's parameters only (the reference

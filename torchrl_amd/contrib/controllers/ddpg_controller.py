@@ -79,7 +79,7 @@ class DDPGController(Controller):
                             lambda: [self._target_actor.data, self._target_critic.data], self.device,
                             graph and not self._sync.enabled)
 
-    # the whole step as 11 phases in one launch, or 11 launches (csrc/trl_offpolicy.hip) for two-hidden-layer stacks (eager, or captured once and replayed with graph=True: the Adam step counts then live on the device);
+    # the whole step as 10 phases in one launch, or 10 launches (csrc/trl_offpolicy.hip) for two-hidden-layer stacks (eager, or captured once and replayed with graph=True: the Adam step counts then live on the device);
     # TRL_FUSED_LEARN=0 keeps the autograd path
     self._fused = None
     if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':

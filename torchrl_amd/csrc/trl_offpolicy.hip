@@ -6,7 +6,7 @@
 //
 // At these sizes a step is ~170 MFLOP: nothing is bound by arithmetic or by HBM (every operand is
 // L2-resident), the step is bound by HOW MANY dependent launches it takes.  Built from BLAS calls
-// and elementwise kernels it is ~70 launches; here it is 11 (DDPG) / 6 (DQN):
+// and elementwise kernels it is ~70 launches; here it is 10 phases (DDPG: in one launch) / 6 launches (DQN):
 //   * one launch = one *phase*: up to 4 independent matrix products of the step that have the same
 //     dependency depth (e.g. layer 1 of actor, target actor and critic), each cut into 16x16 output
 //     tiles, one workgroup per tile, so a phase fills 100-400 CUs;
@@ -79,6 +79,12 @@ struct Tile {
   float *gout;
   int64_t w_off, b_off;  // offsets of the weight / bias in the optimizer's flat buffers
   int upd;               // which Update of the launch
+  // FWD, N == 1, optional: y is the target critic's next-state value; the row's TD target, loss term and the loss's
+  // derivative at `cur` follow in the same epilogue (ddpg_controller.py:105-112) instead of in a phase of their own
+  const float *td_cur, *td_reward, *td_done;
+  float *td_dcur, *td_lterm;
+  float td_gamma, td_hdelta;
+  int td_kind;
 };
 
 struct Update {
@@ -90,18 +96,19 @@ struct Update {
 };
 
 // (one-launch chain only) a phase that is not a set of tiles: the DDPG losses, run by workgroup 0
+// the two loss values: sums over the batch of the per-row terms, by one workgroup that rides in a later phase
 struct LossArgs {
-  const float *cur, *q_pi, *nq, *reward, *done;
-  int B, kind;
-  float gamma, hdelta;
-  float *dcur, *losses_out;
+  const float *lterm, *q_pi;
+  int B;
+  float *losses_out;
 };
 
 struct PhaseArgs {
   Tile t[MAX_TILES];
   Update u[2];
   int nt;
-  int wgs;            // (chain) workgroups' worth of tiles in this phase; 0: the losses entry
+  int wgs;            // workgroups' worth of tiles in this phase
+  int sum_extra;      // 1: one more workgroup (index wgs) forms the losses L
   LossArgs L;
 };
 
@@ -415,6 +422,14 @@ __device__ __forceinline__ void phase_tile(const Tile &T, const Update &U, int t
       if (T.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (T.act == ACT_TANH) v = tanhf(v);
       stf<COH>(T.y + (size_t)m * T.ldy + n, v);
+      if (T.td_dcur != nullptr && n == 0) {
+        const float y = ld1(T.td_reward + m) + ((1.0f - ld1(T.td_done + m)) * T.td_gamma) * v;
+        const float td = ldf<COH>(T.td_cur + m) - y;
+        float g;
+        const float l = trl_loss_elem(td, T.td_kind, T.td_hdelta, &g);
+        stf<COH>(T.td_dcur + m, (1.0f / (float)T.M) * g);
+        stf<COH>(T.td_lterm + m, l);
+      }
     }
     return;
   }
@@ -443,29 +458,14 @@ __device__ __forceinline__ void phase_tile(const Tile &T, const Update &U, int t
   DBG(5);
 }
 
-__global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
-  __shared__ float red[4][256];
-  const int wg = blockIdx.x;
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < MAX_TILES; ++i)
-    if (i < P.nt && wg >= P.t[i].wg0) pi = i;
-  const Tile &T = P.t[pi];
-  phase_tile<false>(T, P.u[T.upd], wg - T.wg0, red);
-}
-
-// y = reward + (1 - done) * gamma * next_q;  critic loss = mean(l(cur - y));  actor loss = -mean(q_pi)
-// (ddpg_controller.py:105-112), and the gradient of the critic loss at cur.  One workgroup.
+// critic loss = mean of the rows' loss terms, actor loss = -mean(q_pi) (ddpg_controller.py:105-112).  One workgroup;
+// thread-strided partial sums, then the block sum: a fixed order.
 template <bool COH>
-__device__ __forceinline__ void ddpg_losses_body(const LossArgs &L, float *red) {
+__device__ __forceinline__ void ddpg_sums_body(const LossArgs &L, float *red) {
   const float invB = 1.0f / (float)L.B;
   float s_c = 0.f, s_a = 0.f;
   for (int b = threadIdx.x; b < L.B; b += 256) {
-    const float y = ld1(L.reward + b) + ((1.0f - ld1(L.done + b)) * L.gamma) * ldf<COH>(L.nq + b);
-    const float td = ldf<COH>(L.cur + b) - y;
-    float g;
-    s_c += trl_loss_elem(td, L.kind, L.hdelta, &g);
-    stf<COH>(L.dcur + b, invB * g);
+    s_c += ldf<COH>(L.lterm + b);
     s_a += ldf<COH>(L.q_pi + b);
   }
   s_c = trl_block_sum<4>(s_c, red);
@@ -476,11 +476,23 @@ __device__ __forceinline__ void ddpg_losses_body(const LossArgs &L, float *red) 
   }
 }
 
-__global__ __launch_bounds__(256) void k_ddpg_losses(LossArgs L) {
-  __shared__ float red[4];
-  ddpg_losses_body<false>(L, red);
+__global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
+  __shared__ float red[4][256];
+  const int wg = blockIdx.x;
+  if (P.sum_extra && wg == P.wgs) {
+    ddpg_sums_body<false>(P.L, &red[0][0]);
+    return;
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TILES; ++i)
+    if (i < P.nt && wg >= P.t[i].wg0) pi = i;
+  const Tile &T = P.t[pi];
+  phase_tile<false>(T, P.u[T.upd], wg - T.wg0, red);
 }
 
+// y = reward + (1 - done) * gamma * next_q;  critic loss = mean(l(cur - y));  actor loss = -mean(q_pi)
+// (ddpg_controller.py:105-112), and the gradient of the critic loss at cur.  One workgroup.
 // ---- the whole chain in ONE launch: every workgroup walks the phases, taking the tiles wg, wg + gridDim.x, ... of each,
 // with a device-wide barrier between two phases.  All workgroups are resident (the host launches at most two per CU),
 // the waits are bounded (a launch that lost a workgroup ends with wrong numbers rather than hanging the GPU).
@@ -525,16 +537,17 @@ __global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ tab
     }
 #endif
     const PhaseArgs &P = *(const PhaseArgs *)(tab + p * PW);
-    if (P.wgs == 0) {
-      if (blockIdx.x == 0) {
-        union { LossArgs l; int w[sizeof(LossArgs) / 4]; } L;
-        const int *lsrc = (const int *)&P.L;
+    {
+      for (int wg = blockIdx.x; wg < P.wgs + P.sum_extra; wg += gridDim.x) {
+        if (wg == P.wgs) {      // (sum_extra) the losses of the phase before
+          union { LossArgs l; int w[sizeof(LossArgs) / 4]; } L;
+          const int *lsrc = (const int *)&P.L;
 #pragma unroll
-        for (int i = 0; i < (int)(sizeof(LossArgs) / 4); ++i) L.w[i] = __builtin_amdgcn_readfirstlane(lsrc[i]);
-        ddpg_losses_body<true>(L.l, &red[0][0]);
-      }
-    } else {
-      for (int wg = blockIdx.x; wg < P.wgs; wg += gridDim.x) {
+          for (int i = 0; i < (int)(sizeof(LossArgs) / 4); ++i) L.w[i] = __builtin_amdgcn_readfirstlane(lsrc[i]);
+          ddpg_sums_body<true>(L.l, &red[0][0]);
+          __syncthreads();
+          continue;
+        }
         int pi = 0;
 #pragma unroll
         for (int i = 1; i < MAX_TILES; ++i)
@@ -673,17 +686,14 @@ struct Chain {
     if (n >= MAX_PHASES) { full = true; return; }
     ph[n] = p.a; ph[n].wgs = p.wgs; ++n;
   }
-  void add_losses(const LossArgs &L) {
-    if (n >= MAX_PHASES) { full = true; return; }
-    memset(&ph[n], 0, sizeof(PhaseArgs)); ph[n].L = L; ph[n].wgs = 0; ++n;
-  }
+  // one more workgroup in the phase added last: the two loss values from the rows' terms
+  void add_sums(const LossArgs &L) { ph[n - 1].L = L; ph[n - 1].sum_extra = 1; }
 };
 
 int run_launches(const Chain &c, hipStream_t st, const char *what) {
   TRL_REQUIRE(!c.full, "%s: internal: more than %d phases", what, MAX_PHASES);
   for (int i = 0; i < c.n; ++i) {
-    if (c.ph[i].wgs == 0) hipLaunchKernelGGL(k_ddpg_losses, dim3(1), dim3(256), 0, st, c.ph[i].L);
-    else hipLaunchKernelGGL(k_phase, dim3(c.ph[i].wgs), dim3(256), 0, st, c.ph[i]);
+    hipLaunchKernelGGL(k_phase, dim3(c.ph[i].wgs + c.ph[i].sum_extra), dim3(256), 0, st, c.ph[i]);
     TRL_CHECK_LAUNCH(what);
   }
   return TRL_OK;
@@ -701,7 +711,7 @@ int run_chain(const Chain &c, const void *ws, hipStream_t st, const char *what) 
   PhaseArgs *tab = cs->tables + (size_t)slot * MAX_PHASES;
   memcpy(tab, c.ph, sizeof(PhaseArgs) * c.n);
   int wgs = 1;
-  for (int i = 0; i < c.n; ++i) wgs = c.ph[i].wgs > wgs ? c.ph[i].wgs : wgs;
+  for (int i = 0; i < c.n; ++i) wgs = c.ph[i].wgs + c.ph[i].sum_extra > wgs ? c.ph[i].wgs + c.ph[i].sum_extra : wgs;
   wgs = wgs < cs->max_wgs ? wgs : cs->max_wgs;
 #ifdef TRL_TUNING
   if (const char *e = getenv("TRL_CHAIN_WGS")) wgs = atoi(e) < wgs ? atoi(e) : wgs;     // A/B runs of tools/ only
@@ -806,7 +816,7 @@ struct Carve {
 
 struct DdpgWs {
   float *a_h0, *a_h1, *ta_h0, *ta_h1, *a_pi, *a_next;
-  float *c_h0, *c_h1, *p_h0, *p_h1, *tc_h0, *tc_h1, *cur, *q_pi, *nq, *dcur;
+  float *c_h0, *c_h1, *p_h0, *p_h1, *tc_h0, *tc_h1, *cur, *q_pi, *nq, *dcur, *lterm;
   float *g_p0, *g_c0, *dz2, *g_a0, *g_a1;
   size_t floats;
   DdpgWs(float *base, const trl_mlp_desc *actor, const trl_mlp_desc *critic, size_t B) {
@@ -818,7 +828,7 @@ struct DdpgWs {
     c_h0 = c.take(B * critic->dims[1]); c_h1 = c.take(B * critic->dims[2]);
     p_h0 = c.take(B * critic->dims[1]); p_h1 = c.take(B * critic->dims[2]);
     tc_h0 = c.take(B * critic->dims[1]); tc_h1 = c.take(B * critic->dims[2]);
-    cur = c.take(B); q_pi = c.take(B); nq = c.take(B); dcur = c.take(B);
+    cur = c.take(B); q_pi = c.take(B); nq = c.take(B); dcur = c.take(B); lterm = c.take(B);
     g_p0 = c.take(B * critic->dims[1]); g_c0 = c.take(B * critic->dims[1]);
     dz2 = c.take(B * A);
     g_a0 = c.take(B * actor->dims[1]); g_a1 = c.take(B * actor->dims[2]);
@@ -936,13 +946,11 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
     Phase ph;
     add_fwd(ph, B, W.p_h1, Hc1, nullptr, 0, cr->w[2], cr->b[2], 1, ACT_NONE, W.q_pi);
     add_fwd(ph, B, W.tc_h1, Hc1, nullptr, 0, tc->w[2], tc->b[2], 1, ACT_NONE, W.nq);
+    // y = reward + (1 - done) * gamma * nq, the critic loss's row terms and its derivative at `cur` in that tile's epilogue
+    Tile &T = ph.a.t[ph.a.nt - 1];
+    T.td_cur = W.cur; T.td_reward = reward; T.td_done = done; T.td_dcur = W.dcur; T.td_lterm = W.lterm;
+    T.td_gamma = (float)gamma; T.td_hdelta = (float)huber_delta; T.td_kind = (int)kind;
     ch.add(ph);
-  }
-  {
-    LossArgs L;
-    L.cur = W.cur; L.q_pi = W.q_pi; L.nq = W.nq; L.reward = reward; L.done = done; L.B = B; L.kind = (int)kind;
-    L.gamma = (float)gamma; L.hdelta = (float)huber_delta; L.dcur = W.dcur; L.losses_out = losses_out;
-    ch.add_losses(L);
   }
 
   const Grad G_p1 = g_virtual(nullptr, -1.0f / (float)B, 1, cr->w[2], W.p_h1);   // d(-mean Q)/d p_h1
@@ -952,6 +960,9 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
     add_dx(ph, B, G_p1, Hc1, cr->w[1], Hc0, 0, Hc0, ACT_RELU, W.p_h0, Hc0, W.g_p0, nullptr);
     add_dx(ph, B, G_c1, Hc1, cr->w[1], Hc0, 0, Hc0, ACT_RELU, W.c_h0, Hc0, W.g_c0, nullptr);
     ch.add(ph);
+    LossArgs L;      // (the loss values themselves: nothing waits for them, one extra workgroup of this phase sums them)
+    L.lterm = W.lterm; L.q_pi = W.q_pi; L.B = B; L.losses_out = losses_out;
+    ch.add_sums(L);
   }
   {  // critic layer 1's gradient (+ update); actor path: through critic layer 0's action columns and the tanh
     Phase ph;

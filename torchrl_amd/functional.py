@@ -874,7 +874,7 @@ class _FusedOffPolicy:
 
 
 class FusedDdpgLearn(_FusedOffPolicy):
-  """DDPGController.learn's device work as 11 phases -- one launch (k_chain), or one per phase -- (C ABI trl_ddpg_learn_fused,
+  """DDPGController.learn's device work as 10 phases -- one launch (k_chain), or one per phase -- (C ABI trl_ddpg_learn_fused,
   csrc/trl_offpolicy.hip) for two-hidden-layer actor / critic stacks whose parameters live in
   optim.FlatParams buffers.  Built once per controller; a call is one foreign call."""
 
