@@ -85,23 +85,36 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
 
   const int kb0 = s * a.bps;
   const int kb1 = min(a.kblocks, kb0 + a.bps);
-  Operands cur, nxt;
-  if (kb0 < kb1) fwd_load(cur, xr, wr, kb0 * KB);
-  for (int kb = kb0; kb < kb1; ++kb) {
-    const bool more = kb + 1 < kb1;
-    if (more) fwd_load(nxt, xr, wr, (kb + 1) * KB);
+  // Three operand sets in rotation: the loads of k block kb + 2 are issued before the 64 MFMAs of block kb, so a
+  // block's operands have two blocks' worth of MFMA time (~3.4 us) to arrive; with one block ahead (~1.7 us) the
+  // stream from HBM / L2 did not always make it and the wave stalled at the top of a block.
+  auto mma = [&](const Operands &o) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a0 = ub(cur.xa[0][q], j), a1 = ub(cur.xa[1][q], j);
-        const float b0 = cur.wb[0][q][j], b1 = cur.wb[1][q][j];
+        const float a0 = ub(o.xa[0][q], j), a1 = ub(o.xa[1][q], j);
+        const float b0 = o.wb[0][q][j], b1 = o.wb[1][q][j];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
-    if (more) cur = nxt;
+  };
+  Operands o0, o1, o2;
+  if (kb0 < kb1) fwd_load(o0, xr, wr, kb0 * KB);
+  if (kb0 + 1 < kb1) fwd_load(o1, xr, wr, (kb0 + 1) * KB);
+  for (int kb = kb0; kb < kb1; kb += 3) {
+    if (kb + 2 < kb1) fwd_load(o2, xr, wr, (kb + 2) * KB);
+    mma(o0);
+    if (kb + 1 < kb1) {
+      if (kb + 3 < kb1) fwd_load(o0, xr, wr, (kb + 3) * KB);
+      mma(o1);
+    }
+    if (kb + 2 < kb1) {
+      if (kb + 4 < kb1) fwd_load(o1, xr, wr, (kb + 4) * KB);
+      mma(o2);
+    }
   }
   // accumulator layout: lane l, register r holds (row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31)
   float *ws = a.ws + ((size_t)pz * a.S + s) * a.Bpad * a.N;
