@@ -13,11 +13,16 @@
  *     (torch tensors' data_ptr()); `*_h` pointers are HOST pointers.
  *   - `stream` is a hipStream_t (void* here so the header needs no HIP include);
  *     NULL is the legacy default stream.  Nothing here allocates, frees or
- *     synchronises: work is enqueued on `stream` and the call returns.
+ *     synchronises: work is enqueued on `stream` and the call returns.  ONE exception, switched
+ *     off by trl_offpolicy_set_chain(0): the one-launch form of trl_ddpg_learn_fused allocates 1 KB
+ *     of device memory and a ring of pinned host memory at its first call with a workspace, and
+ *     waits for its own launch of 16 calls back before reusing that launch's ring slot (never in
+ *     practice: that launch finished long before).
  *   - thread-compatible.  Process-wide state is limited to: the thread-local error text; the
  *     mutex-guarded jump-ahead polynomial cache of trl_randperm_prefix (a pure function of the
  *     skip length, so it never changes a result); the per-device address of the static scratch
- *     array of the no-allocation entry point at the end of this header.  Nothing reads the
+ *     array of the no-allocation entry point at the end of this header; the speculation worker of
+ *     trl_randperm_prefix_ahead; the chain switch and per-workspace chain state above.  Nothing reads the
  *     environment: tuning / ablation switches exist only in the -DTRL_TUNING diagnostic build
  *     (torchrl_amd/_build.py --tuning -> lib/libtrl_hip_tune.so, used by tools/ only).
  */
