@@ -15,14 +15,14 @@
  *     NULL is the legacy default stream.  Nothing here allocates, frees or
  *     synchronises: work is enqueued on `stream` and the call returns.  ONE exception, switched
  *     off by trl_offpolicy_set_chain(0): the one-launch form of trl_ddpg_learn_fused allocates 1 KB
- *     of device memory and a ring of pinned host memory at its first call with a workspace, and
+ *     of device memory and a ring of pinned host memory at its first call on a stream, and
  *     waits for its own launch of 16 calls back before reusing that launch's ring slot (never in
  *     practice: that launch finished long before).
  *   - thread-compatible.  Process-wide state is limited to: the thread-local error text; the
  *     mutex-guarded jump-ahead polynomial cache of trl_randperm_prefix (a pure function of the
  *     skip length, so it never changes a result); the per-device address of the static scratch
  *     array of the no-allocation entry point at the end of this header; the speculation worker of
- *     trl_randperm_prefix_ahead; the chain switch and per-workspace chain state above.  Nothing reads the
+ *     trl_randperm_prefix_ahead; the chain switch and per-stream chain state above.  Nothing reads the
  *     environment: tuning / ablation switches exist only in the -DTRL_TUNING diagnostic build
  *     (torchrl_amd/_build.py --tuning -> lib/libtrl_hip_tune.so, used by tools/ only).
  */
@@ -413,10 +413,11 @@ int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_desc *critic, 
 /* No counterpart in the reference (a switch for tests and measurements).  trl_ddpg_learn_fused issues its chain of
  * phases as ONE launch (every workgroup walks the phases, a device-wide barrier between two of them; data handed
  * from phase to phase goes through agent-scope accesses) unless the optimizer state lives on the device (graph
- * capture).  on = 0: one launch per phase, as before; the two forms give the same bits.  The one-launch form keeps,
- * per `ws` pointer, 256 B of device memory and a small ring of pinned host memory for the phase tables, allocated at
- * the first call with that workspace and kept until the process ends; calls that share a `ws` must be on one stream
- * (they already must: they share the scratch).  Process-wide; default on. */
+ * capture, or `stream` is hipStreamPerThread).  on = 0: one launch per phase, as before; the two forms give the same
+ * bits.  The one-launch form keeps, per (device, stream), 1 KB of device memory and a small ring of pinned host memory
+ * for the phase tables, allocated at the first call on that stream and kept until the process ends (launches on one
+ * stream run one after the other, so they share the barrier block; the count is bounded by the number of streams,
+ * not of learners).  Two host threads must not call it on the SAME stream at the same time.  Process-wide; default on. */
 void trl_offpolicy_set_chain(int32_t on);
 
 /* DQNController.learn up to the optimizer step (dqn_controller.py:61-83; the periodic hard sync

@@ -169,6 +169,41 @@ def test_ddpg_one_launch_chain_is_the_launch_chain_bit_for_bit(S, A, hidden, B):
     assert torch.equal(a, b)
 
 
+def test_ddpg_one_launch_chain_state_is_per_stream_and_shared_by_learners():
+  """The one-launch form keeps its barrier block and table ring per (device, stream): two learners (two workspaces)
+  taking turns on one stream share them, and a learner on a side stream gets its own.  Every learner ends with the
+  bits the launch form gives it."""
+  from torchrl_amd import _lib
+  S, A, hidden, B = 3, 1, 64, 128
+
+  def run(chain, side):
+    _lib.lib().trl_offpolicy_set_chain(chain)
+    rs = np.random.RandomState(11)
+    torch.manual_seed(5)
+    ctls = [DDPGController(S, A, -1.0, 1.0, actor_lr=1e-3, critic_lr=1e-3, tau=0.05, device=DEV, hidden=hidden)
+            for _ in range(2)]
+    for c in ctls:
+      for net in (c.actor, c.critic, c.target_actor, c.target_critic):
+        _perturb(net, rs, 0.05)
+    batches = [[t.to(DEV) for t in _batch(rs, B, S, A)] for _ in range(20)]       # 20 > the ring's 16 slots
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream() if side else torch.cuda.current_stream()
+    with torch.cuda.stream(st):
+      for i, b in enumerate(batches):
+        ctls[i % 2].learn(*b)
+    torch.cuda.synchronize()
+    return [t.data.clone() for c in ctls for t in (c._actor, c._critic, c._target_actor, c._target_critic)]
+
+  try:
+    ref = run(0, False)
+    for side in (False, True):
+      got = run(1, side)
+      for a, b in zip(ref, got):
+        assert torch.equal(a, b), side
+  finally:
+    _lib.lib().trl_offpolicy_set_chain(1)
+
+
 DQN_SHAPES = [(4, 2, 128, 256), (4, 2, 128, 32), (8, 6, (64, 32), 48), (33, 18, (256, 128), 128)]
 
 

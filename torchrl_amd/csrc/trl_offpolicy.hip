@@ -631,8 +631,10 @@ void add_dw(Phase &ph, int B, Grad G, int M, const float *x1, int K1, const floa
   T.G = G; T.x1 = x1; T.K1 = K1; T.x2 = x2; T.K2 = K2; T.w_off = w_off; T.b_off = b_off; T.upd = upd;
 }
 
-// ---- the one-launch chain's host state, one per caller workspace: a barrier block in device memory and a ring of
-// phase tables in pinned host memory (a slot is reused only after the launch that read it has finished)
+// ---- the one-launch chain's host state, one per (device, stream): a barrier block in device memory and a ring of
+// phase tables in pinned host memory (a slot is reused only after the launch that read it has finished).  Launches
+// on one stream run one after the other, so they can share the barrier block; the number of states is bounded by the
+// number of streams the caller uses, whatever the number of learners and workspaces.
 constexpr int CHAIN_SLOTS = 16;
 struct ChainState {
   unsigned *bar = nullptr;          // device, 256 dwords, zeroed once; the barrier leaves it clean
@@ -643,17 +645,17 @@ struct ChainState {
   int max_wgs = 0;                  // resident-workgroup budget of the device: two per CU
 };
 std::mutex g_chain_mu;
-std::unordered_map<uint64_t, ChainState *> g_chains;     // key: workspace address ^ (device << 56)
+std::unordered_map<uint64_t, ChainState *> g_chains;     // key: stream handle ^ (device << 56)
 int g_chain_on = 1;
 
-ChainState *chain_state(const char *fn, const void *ws) {
+ChainState *chain_state(const char *fn, hipStream_t st) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     trl_set_error("%s: hipGetDevice failed", fn);
     return nullptr;
   }
-  const uint64_t key = (uint64_t)(uintptr_t)ws ^ ((uint64_t)dev << 56);
+  const uint64_t key = (uint64_t)(uintptr_t)st ^ ((uint64_t)dev << 56);
   std::lock_guard<std::mutex> lk(g_chain_mu);
   auto it = g_chains.find(key);
   if (it != g_chains.end()) return it->second;
@@ -699,9 +701,9 @@ int run_launches(const Chain &c, hipStream_t st, const char *what) {
   return TRL_OK;
 }
 
-int run_chain(const Chain &c, const void *ws, hipStream_t st, const char *what) {
+int run_chain(const Chain &c, hipStream_t st, const char *what) {
   TRL_REQUIRE(!c.full, "%s: internal: more than %d phases", what, MAX_PHASES);
-  ChainState *cs = chain_state(what, ws);
+  ChainState *cs = chain_state(what, st);
   if (!cs) return TRL_EHIP;
   const int slot = (int)(cs->n++ % CHAIN_SLOTS);
   if (cs->used[slot] && hipEventSynchronize(cs->ev[slot]) != hipSuccess) {    // (16 launches back: long finished)
@@ -996,8 +998,9 @@ extern "C" int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_des
     (void)hipGetLastError();
     cap = hipStreamCaptureStatusNone;
   }
-  if (g_chain_on && !actor_opt->dev_state && cap == hipStreamCaptureStatusNone) {
-    if ((rc = run_chain(ch, ws, st, fn))) return rc;
+  // (hipStreamPerThread is one handle for a different stream in every thread: no shared barrier block for it)
+  if (g_chain_on && !actor_opt->dev_state && cap == hipStreamCaptureStatusNone && st != hipStreamPerThread) {
+    if ((rc = run_chain(ch, st, fn))) return rc;
   } else if ((rc = run_launches(ch, st, fn))) {
     return rc;
   }
