@@ -27,7 +27,43 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ float ub(unsigned int w, int j) { return (float)((w >> (8 * j)) & 255u); }
+
+// ---- operands of v_mfma_f32_32x32x16_bf16 that lose nothing (the forward kernel).
+// A uint8 is exactly a bf16 (8 significant bits), and an f32 is exactly the sum of three bf16 (hi = its top 16 bits,
+// mid = the top 16 bits of the exact remainder, lo = what is then left: 8 + 8 + 8 significant bits).  So
+// x_u8 * w = x * hi + x * mid + x * lo with every partial product exact (8 x 8 bits) and the sums taken in the MFMA's
+// f32 accumulators: three 32-cycle instructions over 16 k instead of eight 64-cycle f32 ones, the same values up to the
+// order of the f32 additions.
+// the top halves of two floats as one dword of two bf16: low 16 bits from a, high 16 bits from b
+__device__ __forceinline__ unsigned int top2(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+// 8 consecutive uint8 (two dwords) as one operand
+__device__ __forceinline__ u4v x_operand(unsigned int w0, unsigned int w1) {
+  u4v r;
+  r[0] = top2(ub(w0, 0), ub(w0, 1));
+  r[1] = top2(ub(w0, 2), ub(w0, 3));
+  r[2] = top2(ub(w1, 0), ub(w1, 1));
+  r[3] = top2(ub(w1, 2), ub(w1, 3));
+  return r;
+}
+// 8 consecutive f32 as three operands: part[0] + part[1] + part[2] = w, exactly
+__device__ __forceinline__ void w_operands(const f4v &a, const f4v &b, u4v (&part)[3]) {
+  typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const f2v w = d < 2 ? f2v{a[2 * d], a[2 * d + 1]} : f2v{b[2 * d - 4], b[2 * d - 3]};
+    part[0][d] = top2(w[0], w[1]);
+    const f2v r = w - f2v{top16(w[0]), top16(w[1])};
+    part[1][d] = top2(r[0], r[1]);
+    const f2v l = r - f2v{top16(r[0]), top16(r[1])};
+    part[2][d] = top2(l[0], l[1]);
+  }
+}
 
 constexpr int FWD_MT = 128, FWD_NT = 128;   // workgroup tile (4 waves as 2 x 2 of 64 x 64)
 constexpr int KB = 32;                      // k per block: 16 per lane half
@@ -88,33 +124,52 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
   // Three operand sets in rotation: the loads of k block kb + 2 are issued before the 64 MFMAs of block kb, so a
   // block's operands have two blocks' worth of MFMA time (~3.4 us) to arrive; with one block ahead (~1.7 us) the
   // stream from HBM / L2 did not always make it and the wave stalled at the top of a block.
+  // A lane's 16 consecutive k are two MFMA k groups of 8 (slot (lane half, j) <-> k = 16 * half + 8 m + j on both
+  // operands); per group and tile: x * lo, x * mid, x * hi, smallest first.  24 MFMAs of 32 cycles per block of 32 k
+  // where the exact-f32 instruction took 64 of 64 cycles.
   auto mma = [&](const Operands &o) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int m = 0; m < 2; ++m) {
+      u4v xo[2], wp[2][3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a0 = ub(o.xa[0][q], j), a1 = ub(o.xa[1][q], j);
-        const float b0 = o.wb[0][q][j], b1 = o.wb[1][q][j];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      }
+      for (int i = 0; i < 2; ++i) xo[i] = x_operand(o.xa[i][2 * m], o.xa[i][2 * m + 1]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) w_operands(o.wb[t][2 * m], o.wb[t][2 * m + 1], wp[t]);
+#pragma unroll
+      for (int p = 2; p >= 0; --p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, xo[i]),
+                                                                __builtin_bit_cast(bf8v, wp[t][p]), acc[i][t], 0, 0, 0);
+    }
+  };
+  // The MFMAs are unconditional (a branch around them makes the compiler copy all 64 accumulators at the join): a set
+  // beyond the split's last block holds zeros, which add nothing.  The host makes a split a multiple of three blocks,
+  // so only the launch's last split runs such a block.
+  auto load = [&](Operands &o, int kb) {
+    if (kb < kb1) {
+      fwd_load(o, xr, wr, kb * KB);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) o.xa[i] = u4v{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o.wb[t][q] = f4v{0.f, 0.f, 0.f, 0.f};
+    }
   };
   Operands o0, o1, o2;
-  if (kb0 < kb1) fwd_load(o0, xr, wr, kb0 * KB);
-  if (kb0 + 1 < kb1) fwd_load(o1, xr, wr, (kb0 + 1) * KB);
+  load(o0, kb0);
+  load(o1, kb0 + 1);
   for (int kb = kb0; kb < kb1; kb += 3) {
-    if (kb + 2 < kb1) fwd_load(o2, xr, wr, (kb + 2) * KB);
+    load(o2, kb + 2);
     mma(o0);
-    if (kb + 1 < kb1) {
-      if (kb + 3 < kb1) fwd_load(o0, xr, wr, (kb + 3) * KB);
-      mma(o1);
-    }
-    if (kb + 2 < kb1) {
-      if (kb + 4 < kb1) fwd_load(o1, xr, wr, (kb + 4) * KB);
-      mma(o2);
-    }
+    load(o0, kb + 3);
+    mma(o1);
+    load(o1, kb + 4);
+    mma(o2);
   }
   // accumulator layout: lane l, register r holds (row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31)
   float *ws = a.ws + ((size_t)pz * a.S + s) * a.Bpad * a.N;
@@ -284,7 +339,7 @@ bool fwd_plan(int64_t B, int32_t N, int32_t K, int P, FwdPlan *p) {
   p->Bpad = p->mtiles * FWD_MT;
   p->kblocks = K / KB;
   const int tiles = p->mtiles * (N / FWD_NT) * P;
-  int total_wgs = 512;                                 // ~2 workgroups per CU over the whole launch (flat optimum 256-768: tools/u8_fwd_sweep.py)
+  int total_wgs = 256;                                 // one workgroup per CU over the whole launch (tools/u8_fwd_sweep.py: 85 us per step's chain at 256, 92-100 at 192 / 384-1536)
 #ifdef TRL_TUNING                                      // diagnostic build: sweep of the split count (tools/u8_fwd_sweep.py)
   if (const char *t = getenv("TRL_U8_FWD_WGS"))
     if (atoi(t) > 0) total_wgs = atoi(t);
@@ -294,6 +349,7 @@ bool fwd_plan(int64_t B, int32_t N, int32_t K, int P, FwdPlan *p) {
   int bps = (p->kblocks + target - 1) / target;
   const int min_bps = (p->kblocks + RED_SLICES * RED_MAX_PER_SLICE - 1) / (RED_SLICES * RED_MAX_PER_SLICE);
   p->bps = bps > min_bps ? bps : min_bps;              // the reduce launch holds at most 256 partial tiles per output
+  p->bps = (p->bps + 2) / 3 * 3;                       // whole rounds of the kernel's three operand sets
   p->S = (p->kblocks + p->bps - 1) / p->bps;
   return true;
 }
