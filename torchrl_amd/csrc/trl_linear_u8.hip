@@ -13,9 +13,12 @@
 //                                                            fixed order by a second launch
 //   wgrad     dW[N, K] = g[B, N]^T @ x_u8[B, K]              one pass, each output written once
 //
-// Both run on v_mfma_f32_32x32x2_f32 (exact f32 products and accumulation); the MFMA sums over its
-// two k slots, and which k sits in which slot is free as long as A and B agree, so a lane walks 16
-// CONSECUTIVE k of its row (one 16 B load = 16 uint8 of x, 4 x 16 B of W) instead of stride-2 ones.
+// Both run on v_mfma_f32_32x32x16_bf16 with operands that lose nothing: a uint8 IS a bf16, and the f32 operand
+// (the weight; in wgrad the gradient) goes in as its three exact bf16 parts, so every partial product is exact and the
+// sums are taken in the MFMA's f32 accumulators (see x_operand / w_operands below; until the end of round 2 this was
+// v_mfma_f32_32x32x2_f32, eight 64-cycle instructions per 16 k where three 32-cycle ones do now).  The MFMA sums
+// over its 16 k slots, and which k sits in which slot is free as long as A and B agree, so a lane walks 16
+// CONSECUTIVE k of its row (one 16 B load = 16 uint8 of x, 4 x 16 B of W) as two groups of 8.
 #include <stdlib.h>
 #include <string.h>
 
@@ -302,10 +305,25 @@ __global__ __launch_bounds__(256) void k_lin_u8_wgrad(WgradArgs a) {
         xn[j] = *(const unsigned int *)(x2 + (size_t)j * a.K);
       }
     }
+    // A lane's 16 batch rows are two MFMA k groups of 8 (slot (lane half, jj) <-> row 16 h + 8 m + jj on both operands);
+    // g as its three exact bf16 parts, byte t of the 8 x dwords as the operand of tile t: 24 MFMAs of 32 cycles per 32
+    // rows where the exact-f32 instruction took 64 of 64 cycles, the same values up to the order of the f32 additions.
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int m = 0; m < 2; ++m) {
+      u4v gq[3], xo[4];
+      w_operands(f4v{ga[8 * m], ga[8 * m + 1], ga[8 * m + 2], ga[8 * m + 3]},
+                 f4v{ga[8 * m + 4], ga[8 * m + 5], ga[8 * m + 6], ga[8 * m + 7]}, gq);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j], ub(xa[j], t), acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) xo[t][d] = top2(ub(xa[8 * m + 2 * d], t), ub(xa[8 * m + 2 * d + 1], t));
+#pragma unroll
+      for (int p = 2; p >= 0; --p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, gq[p]), __builtin_bit_cast(bf8v, xo[t]),
+                                                           acc[t], 0, 0, 0);
+    }
     if (more) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
