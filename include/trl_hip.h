@@ -275,7 +275,9 @@ int trl_linear_bwd(const float *dy, const float *y, const float *x, const float 
  * (torchrl/utils/storage.py:65-67): uint8 -> float32 is exact, so the values are the same and the
  * batch never exists as float32.  N % 128 == 0, K % 32 == 0; `ws` is a caller-owned device scratch of
  * trl_linear_u8_fwd_workspace_bytes(B, N, K) bytes (split-K partial tiles, summed in a fixed order).
- * trl_linear_u8_wgrad: dw[N, K] = g[B, N]^T @ float(x)  (OVERWRITTEN; B % 32 == 0, K % 4 == 0). */
+ * trl_linear_u8_wgrad: dw[N, K] = g[B, N]^T @ float(x)  (OVERWRITTEN; B % 32 == 0, K % 4 == 0).
+ * Arithmetic: the uint8 operand is exactly a bf16 and the f32 operand goes in as its three exact bf16 parts, so every
+ * partial product is exact and the sums are f32 (the MFMA's accumulators): f32 results, no reduced precision. */
 int64_t trl_linear_u8_fwd_workspace_bytes(int64_t B, int32_t N, int32_t K);
 int trl_linear_u8_fwd(const uint8_t *x, const float *w, const float *b, int64_t B, int32_t K, int32_t N,
                       int32_t act, float *y, void *ws, void *stream);
