@@ -68,7 +68,8 @@ __device__ __forceinline__ void w_operands(const f4v &a, const f4v &b, u4v (&par
   }
 }
 
-constexpr int FWD_MT = 128, FWD_NT = 128;   // workgroup tile (4 waves as 2 x 2 of 64 x 64)
+constexpr int FWD_MT = 128, FWD_NT = 128;   // workgroup tile: 4 waves of 128 rows x 32 columns each (W is 4 B per element and x 1 B:
+                                            // the tall wave tile loads the fewest bytes per MFMA, 8 KB per block against 10 KB for 64 x 64)
 constexpr int KB = 32;                      // k per block: 16 per lane half
 
 constexpr int MAX_PROBLEMS = 3;   // the three first-layer passes of a Double-DQN step share one launch
@@ -80,16 +81,17 @@ struct FwdArgs {
   int B, N, K, Bpad, bps, kblocks, S;
 };
 
+constexpr int WI = 4, WT = 1;   // 32 x 32 tiles per wave: rows x columns
 struct Operands {
-  u4v xa[2];       // 16 uint8 of two rows
-  f4v wb[2][4];    // 16 floats of two weight rows
+  u4v xa[WI];      // 16 uint8 of each row
+  f4v wb[WT][4];   // 16 floats of each weight row
 };
 
-__device__ __forceinline__ void fwd_load(Operands &o, const uint8_t *const (&xr)[2], const float *const (&wr)[2], int k) {
+__device__ __forceinline__ void fwd_load(Operands &o, const uint8_t *const (&xr)[WI], const float *const (&wr)[WT], int k) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) o.xa[i] = *(const u4v *)(xr[i] + k);
+  for (int i = 0; i < WI; ++i) o.xa[i] = *(const u4v *)(xr[i] + k);
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < WT; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) o.wb[t][q] = *(const f4v *)(wr[t] + k + 4 * q);
 }
@@ -102,23 +104,23 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
   const int ntn = a.N / FWD_NT;
   const int mt = blockIdx.y / ntn, nt = blockIdx.y - mt * ntn;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
-  const int r0 = mt * FWD_MT + (wave >> 1) * 64, n0 = nt * FWD_NT + (wave & 1) * 64;
-  const uint8_t *xr[2];
-  const float *wr[2];
+  const int r0 = mt * FWD_MT, n0 = nt * FWD_NT + wave * 32;
+  const uint8_t *xr[WI];
+  const float *wr[WT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < WI; ++i) {
     int row = r0 + 32 * i + lr;
     row = row < a.B ? row : a.B - 1;            // padding rows read a valid row; their results are never used
     xr[i] = xbase + (size_t)row * a.K + 16 * kh;
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) wr[t] = wbase + (size_t)(n0 + 32 * t + lr) * a.K + 16 * kh;   // N % 128 == 0: always valid
+  for (int t = 0; t < WT; ++t) wr[t] = wbase + (size_t)(n0 + 32 * t + lr) * a.K + 16 * kh;   // N % 128 == 0: always valid
 
-  f16v acc[2][2];
+  f16v acc[WI][WT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < WT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
@@ -133,17 +135,17 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
   auto mma = [&](const Operands &o) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      u4v xo[2], wp[2][3];
+      u4v xo[WI], wp[WT][3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) xo[i] = x_operand(o.xa[i][2 * m], o.xa[i][2 * m + 1]);
+      for (int i = 0; i < WI; ++i) xo[i] = x_operand(o.xa[i][2 * m], o.xa[i][2 * m + 1]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) w_operands(o.wb[t][2 * m], o.wb[t][2 * m + 1], wp[t]);
+      for (int t = 0; t < WT; ++t) w_operands(o.wb[t][2 * m], o.wb[t][2 * m + 1], wp[t]);
 #pragma unroll
       for (int p = 2; p >= 0; --p)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WI; ++i)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < WT; ++t)
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, xo[i]),
                                                                 __builtin_bit_cast(bf8v, wp[t][p]), acc[i][t], 0, 0, 0);
     }
@@ -156,9 +158,9 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
       fwd_load(o, xr, wr, kb * KB);
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) o.xa[i] = u4v{0u, 0u, 0u, 0u};
+      for (int i = 0; i < WI; ++i) o.xa[i] = u4v{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < WT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) o.wb[t][q] = f4v{0.f, 0.f, 0.f, 0.f};
     }
@@ -177,9 +179,9 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
   // accumulator layout: lane l, register r holds (row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31)
   float *ws = a.ws + ((size_t)pz * a.S + s) * a.Bpad * a.N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < WT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = r0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;   // < Bpad by construction
