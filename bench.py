@@ -633,6 +633,9 @@ def bench_offpolicy(args, rank, world, dev, atari):
                   if getattr(ctl, '_fused', None) is not None else 'eager')},
       'roofline': roof,
   }
+  if atari and not args.f32_frames:
+    res['config']['first_layer_arithmetic'] = ('uint8 x f32 as three exact bf16 partial products per weight (a uint8 is a bf16, an '
+                                               'f32 is three), summed in f32 MFMA accumulators: f32 results, csrc/trl_linear_u8.hip')
   return res, dict(cap=cap, B=B, atari=atari)
 
 
