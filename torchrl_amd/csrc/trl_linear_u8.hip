@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
 
   const int kb0 = s * a.bps;
   const int kb1 = min(a.kblocks, kb0 + a.bps);
-  // Three operand sets in rotation: the loads of k block kb + 2 are issued before the 64 MFMAs of block kb, so a
-  // block's operands have two blocks' worth of MFMA time (~3.4 us) to arrive; with one block ahead (~1.7 us) the
-  // stream from HBM / L2 did not always make it and the wave stalled at the top of a block.
+  // Three operand sets in rotation: the loads of k block kb + 2 are issued before the 24 MFMAs of block kb, so a
+  // block's operands have two blocks' worth of work to arrive (a fourth set, three blocks ahead, measured no gain: the
+  // L1 lookup rate, 64 per load instruction of this layout, is what the loop waits for).
   // A lane's 16 consecutive k are two MFMA k groups of 8 (slot (lane half, j) <-> k = 16 * half + 8 m + j on both
   // operands); per group and tile: x * lo, x * mid, x * hi, smallest first.  24 MFMAs of 32 cycles per block of 32 k
   // where the exact-f32 instruction took 64 of 64 cycles.
