@@ -21,26 +21,40 @@ reference path (per-env Python GAE loop + torch-CPU learn) on a bounded sample.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-from torchrl_amd import functional as F  # noqa: E402
-from torchrl_amd.contrib.controllers import PPOController, A2CController, DDPGController, DQNController  # noqa: E402
-from torchrl_amd.utils.storage import TensorTupleDataset  # noqa: E402
+# torch, torch.distributed and the package are imported by _load() AFTER main() has decided whether this process is a
+# rank or the launcher of N ranks: the launcher (`bench.py --gpus N` outside torch.distributed.run) never imports
+# anything that could touch the GPU.
+np = torch = dist = F = None
+PPOController = A2CController = DDPGController = DQNController = TensorTupleDataset = None
+
+
+def _load():
+  global np, torch, dist, F, PPOController, A2CController, DDPGController, DQNController, TensorTupleDataset
+  import numpy
+  import torch as _torch
+  import torch.distributed as _dist
+  from torchrl_amd import functional as _F
+  from torchrl_amd.contrib import controllers as _c
+  from torchrl_amd.utils.storage import TensorTupleDataset as _T
+  np, torch, dist, F = numpy, _torch, _dist, _F
+  PPOController, A2CController, DDPGController, DQNController = (_c.PPOController, _c.A2CController, _c.DDPGController,
+                                                                  _c.DQNController)
+  TensorTupleDataset = _T
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (MI355X_MICROARCH.md, matrix cores)
 
 
-def parse():
+def parse(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=None)
@@ -76,25 +90,70 @@ def parse():
                   help='HIP-graph replay of learn(); auto = off wherever the whole step is a handful of fused launches '
                        '(ppo, a2c, ddpg, dqn_atari on uint8 frames), on for dqn_atari --f32-frames (BLAS + autograd path)')
   ap.add_argument('--no-graph', action='store_true', help='same as --graph off')
-  return ap.parse_args()
+  return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+  """`bench.py --gpus N` started as ONE process (no WORLD_SIZE in the environment, the way the driver invokes it): start
+  N fresh rank processes with torch.distributed.run, one per GPU over RCCL, relay rank 0's JSON line and the worst exit
+  code.  Called before torch is imported: this process never touches the GPU (a process that has must not exec, and
+  the ranks are children, not replacements)."""
+  assert 'torch' not in sys.modules or torch is None, 'the launcher must run before the GPU stack is loaded'
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:     # a free rendezvous port on the loopback
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env['TRL_BENCH_LAUNCHED'] = '1'
+  print('bench.py: starting %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+  proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  line = None
+  for out in proc.stdout:          # rank 0 prints the one JSON line; anything else on stdout is passed through to stderr
+    t = out.strip()
+    if t.startswith('{') and t.endswith('}') and '"metric"' in t:
+      line = t
+    elif t:
+      print(t, file=sys.stderr, flush=True)
+  rc = proc.wait()
+  if rc != 0:
+    print('bench.py: a rank failed (torch.distributed.run exit code %d)' % rc, file=sys.stderr)
+    return rc
+  if line is None:
+    print('bench.py: the ranks ended without a result line', file=sys.stderr)
+    return 1
+  print(line, flush=True)
+  return 0
 
 
 def setup_dist(args):
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
-  torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-  local = local % max(1, torch.cuda.device_count())
+  backend = os.environ.get('TRL_BENCH_BACKEND', 'nccl')   # 'gloo' lets a 1-GPU box rehearse N ranks
+  ndev = torch.cuda.device_count()
+  if world > 1 and backend == 'nccl' and ndev < world:
+    raise SystemExit('bench.py: %d ranks over RCCL need %d GPUs, this node shows %d (TRL_BENCH_BACKEND=gloo rehearses '
+                     'N ranks on fewer cards)' % (world, world, ndev))
+  torch.cuda.set_device(local % max(1, ndev))
+  local = local % max(1, ndev)
+  ranks_seen = 1
   if world > 1 or os.environ.get('TRL_FORCE_GRADSYNC') == '1':
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
-    backend = os.environ.get('TRL_BENCH_BACKEND', 'nccl')   # 'gloo' lets a 1-GPU box rehearse N ranks
     if backend == 'nccl':
       dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     else:
       dist.init_process_group(backend, rank=rank, world_size=world)
+    # the world the collective library actually formed: a sum of ones over it
+    one = torch.ones(1, device='cuda' if backend == 'nccl' else 'cpu')
+    dist.all_reduce(one)
+    ranks_seen = int(one.item())
   if args.gpus != world and rank == 0:
     print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+  args.ranks_seen = ranks_seen
+  args.backend = backend if (world > 1 or os.environ.get('TRL_FORCE_GRADSYNC') == '1') else None
   return rank, local, world
 
 
@@ -427,9 +486,16 @@ def learn_kernel_roofline(args, ctl, cols, Bk):
   return out
 
 
+def ppo_info(args):
+  hidden = tuple(int(h) for h in args.hidden.split(','))
+  return dict(T=args.T, hidden=hidden, B=args.minibatch or max(1, (args.T * args.N) // 8), epochs=args.epochs)
+
+
 def cpu_baseline_ppo(info):
   """Oracle port of the reference path on the host: per-env compute_return loop
-  (ppo_controller.py:32-51) + learn() minibatches (ppo_controller.py:53-80)."""
+  (ppo_controller.py:32-51) + learn() minibatches (ppo_controller.py:53-80).  Two rows: the bench's own minibatch
+  (`value`) and the reference's minibatch of 64 (examples/ppo.py:92), the latter like-for-like with the GPU line's
+  minibatch_sweep[64] / learn_epoch rows (learn() timed on a bounded run of calls, the step extrapolated the same way)."""
   from oracle import loss_oracle
   from torchrl_amd.contrib.models import ActorCriticNet
   torch.set_num_threads(1)
@@ -447,6 +513,7 @@ def cpu_baseline_ppo(info):
     for c, x in zip(cols, (obs, act, rew, nobs, done, ret, lp, ret - v)):
       c.append(x)
   cols = [torch.cat(c, 0) for c in cols]
+  t_return = time.perf_counter() - t0
   n = n_envs * T
   Bc = min(B, n)
   for _ in range(epochs):
@@ -454,9 +521,20 @@ def cpu_baseline_ppo(info):
       loss_oracle.ppo_learn(net, opt, *[c[s:s + Bc] for c in cols], clip=0.2, alpha=0.5, beta=1e-3,
                             max_grad_norm=1.0)
   dt = time.perf_counter() - t0
+  # the reference's own minibatch: 2,000 consecutive learn() calls of 64 rows, the 4-epoch step extrapolated
+  ncalls, B64 = 2000, 64
+  t1 = time.perf_counter()
+  for i in range(ncalls):
+    s = (i * B64) % (n - B64)
+    loss_oracle.ppo_learn(net, opt, *[c[s:s + B64] for c in cols], clip=0.2, alpha=0.5, beta=1e-3, max_grad_norm=1.0)
+  per_call = (time.perf_counter() - t1) / ncalls
+  dt64 = t_return + epochs * ((n + B64 - 1) // B64) * per_call
   return {'value': round(epochs * n / dt, 1), 'unit': 'transitions/s', 'cores': 1, 'kind': 'port',
           'sample': '%d of the envs x T=%d: per-env torch-CPU GAE loop + %d epochs x minibatch %d learn(), '
                     '1 thread (the reference loops are single-threaded Python); %.1f s' % (n_envs, T, epochs, Bc, dt),
+          'minibatch_64': {'value': round(epochs * n / dt64, 1), 'unit': 'transitions/s', 'us_per_learn_call': round(per_call * 1e6, 1),
+                           'sample': 'the same %d envs; learn() at the reference\'s minibatch of 64 timed on %d consecutive calls, '
+                                     'the %d-epoch step extrapolated (as the GPU line\'s minibatch_sweep does)' % (n_envs, ncalls, epochs)},
           'host_cpus': os.cpu_count()}
 
 
@@ -698,8 +776,13 @@ def run_only(args, dev):
   raise SystemExit('unknown --only entry %r' % e)
 
 
-def main():
-  args = parse()
+def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
+  args = parse(argv)
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.only:
+    # the driver's command shape: one process asked for N GPUs.  Become the launcher -- before anything GPU-side loads
+    return launch_ranks(args, argv)
+  _load()
   if args.no_graph:
     args.graph = 'off'
   # graph replay only where the step is still BLAS + autograd: float32 frames into the flat-frame QNet
@@ -708,7 +791,11 @@ def main():
   dev = torch.device('cuda', local)
   if args.only:
     print(json.dumps(run_only(args, dev)))
-    return
+    return 0
+  cpu_base = None
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != 'a2c':
+    # the host baseline first, so that the GPU phase of the run is one contiguous stretch (a utilisation sampler sees it)
+    cpu_base = cpu_baseline_ppo(ppo_info(args)) if args.workload == 'ppo' else None
   if args.workload == 'ppo':
     res, info = bench_ppo(args, rank, world, dev)
   elif args.workload == 'a2c':
@@ -717,6 +804,10 @@ def main():
     args.no_cpu_baseline = True
   else:
     res, info = bench_offpolicy(args, rank, world, dev, atari=args.workload == 'dqn_atari')
+  res['n_gpus'] = args.ranks_seen if world > 1 else world
+  res['config']['ranks_seen'] = args.ranks_seen
+  res['config']['collective'] = ('%s all-reduce of the flat gradient, one per optimizer step' % ('RCCL' if args.backend == 'nccl' else args.backend)
+                                 if args.backend else 'none (one rank)')
   if rank == 0 and world == 1:
     if args.workload == 'ppo' and not args.no_extras:
       res['kernels'] = [
@@ -744,13 +835,14 @@ def main():
         except Exception as e:  # noqa: BLE001  (an extra must not take the headline line down)
           res['other_workloads'].append({'workload': wl, 'error': str(e)[:300]})
     if not args.no_cpu_baseline:
-      res['cpu_baseline'] = cpu_baseline_ppo(info) if args.workload == 'ppo' else cpu_baseline_offpolicy(info)
+      res['cpu_baseline'] = cpu_base if cpu_base is not None else cpu_baseline_offpolicy(info)
   if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
   if rank == 0:
-    print(json.dumps(res))
+    print(json.dumps(res), flush=True)
+  return 0
 
 
 if __name__ == '__main__':
-  main()
+  sys.exit(main())

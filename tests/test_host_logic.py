@@ -206,3 +206,72 @@ def test_flat_params_fresh_grads_equal_accumulated():
   assert torch.equal(fa.grad, fb.grad) and float(fa.grad.abs().max()) > 0
   assert all(p.grad.data_ptr() == fb.grad.data_ptr() + 4 * off for p, off in zip(fb.params, fb.offsets))
   assert float(fb.params[-1].grad.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------- bench.py --gpus N: the launcher path
+def _fresh_bench():
+  import importlib, sys as _sys
+  _sys.modules.pop('bench', None)
+  return importlib.import_module('bench')
+
+
+def test_bench_gpus_n_starts_n_ranks_before_the_gpu_stack_loads(monkeypatch, capsys):
+  """`python bench.py --gpus N` as ONE process (the driver's command shape) must become the launcher of N rank
+  processes -- torch.distributed.run, loopback rendezvous -- before bench.py has imported torch or the package
+  (nothing GPU-side may be loaded in a process that then starts the ranks), relay rank 0's JSON line and exit 0."""
+  bench = _fresh_bench()
+  monkeypatch.delenv('WORLD_SIZE', raising=False)
+  seen = {}
+
+  class FakeProc:
+    def __init__(self, cmd, env=None, stdout=None, text=None):
+      seen['cmd'], seen['env'] = cmd, env
+      seen['torch_loaded_in_launcher'] = bench.torch is not None
+      self.stdout = iter(['some library chatter\n', '{"metric": "m", "value": 1.0, "n_gpus": 4}\n'])
+
+    def wait(self):
+      return 0
+
+  monkeypatch.setattr(bench.subprocess, 'Popen', FakeProc)
+  monkeypatch.setattr(bench, '_load', lambda: (_ for _ in ()).throw(AssertionError('the launcher loaded the GPU stack')))
+  rc = bench.main(['--gpus', '4', '--steps', '3', '--warmup', '1'])
+  assert rc == 0
+  cmd = seen['cmd']
+  assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nnodes=1' in cmd
+  assert cmd[cmd.index('--nproc-per-node') + 1] == '4'
+  assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+  assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+  assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+  assert seen['torch_loaded_in_launcher'] is False
+  out = capsys.readouterr()
+  assert out.out.strip() == '{"metric": "m", "value": 1.0, "n_gpus": 4}'      # ONE line on stdout, the chatter on stderr
+  assert 'some library chatter' in out.err
+
+
+def test_bench_launcher_reports_a_failed_rank(monkeypatch, capsys):
+  bench = _fresh_bench()
+  monkeypatch.delenv('WORLD_SIZE', raising=False)
+
+  class FakeProc:
+    def __init__(self, *a, **k):
+      self.stdout = iter([])
+
+    def wait(self):
+      return 1
+
+  monkeypatch.setattr(bench.subprocess, 'Popen', FakeProc)
+  assert bench.main(['--gpus', '2']) != 0
+  assert capsys.readouterr().out.strip() == ''
+
+
+def test_bench_is_a_rank_under_torch_distributed_run(monkeypatch):
+  """With WORLD_SIZE in the environment (a rank started by torch.distributed.run, by the driver or by the launcher
+  above) bench.py must NOT launch again."""
+  bench = _fresh_bench()
+  monkeypatch.setenv('WORLD_SIZE', '2')
+  called = {}
+  monkeypatch.setattr(bench, 'launch_ranks', lambda *a: called.setdefault('launched', True))
+  monkeypatch.setattr(bench, '_load', lambda: (_ for _ in ()).throw(KeyboardInterrupt('rank path')))
+  with pytest.raises(KeyboardInterrupt):
+    bench.main(['--gpus', '2'])
+  assert 'launched' not in called
