@@ -170,3 +170,80 @@ def test_production_library_has_no_environment_switches():
     assert rc == -1 and b'null pointer' in lib.trl_last_error()
   finally:
     del os.environ['TRL_GAE_TUNE']
+
+
+def _ahead_stream(seed, n, B, calls, next_n):
+  """`calls` consecutive trl_randperm_prefix_ahead draws from a private MT19937 stream, through the C ABI."""
+  import ctypes as C
+  lib = _lib.lib()
+  mt = np.zeros(624, dtype=np.uint32)
+  left, nxt, hit = C.c_int32(1), C.c_int32(0), C.c_int32(0)
+  _lib.check(lib.trl_mt19937_seed(mt.ctypes.data, C.byref(left), C.byref(nxt), C.c_uint64(seed)))
+  outs = []
+  for _ in range(calls):
+    out = np.empty(B, dtype=np.int64)
+    _lib.check(lib.trl_randperm_prefix_ahead(mt.ctypes.data, C.byref(left), C.byref(nxt), n, B, out.ctypes.data, next_n,
+                                             C.byref(hit)))
+    outs.append(out)
+  return outs, mt.copy(), (left.value, nxt.value)
+
+
+def _direct_stream(seed, n, B, calls):
+  from torchrl_amd.utils.sampler import Mt19937Sampler
+  s = Mt19937Sampler(seed)
+  return [s.randperm_prefix(n, B, jump=False).numpy().copy() for _ in range(calls)], s._mt.copy(), (s._left.value, s._next.value)
+
+
+def test_sampler_ahead_of_time_with_two_host_threads():
+  """ctypes releases the GIL, so two Python threads can be inside trl_randperm_prefix_ahead at once, each with its own
+  generator, batch size and ring length.  The one speculation worker must never have its job rewritten while it runs
+  (round-2 advisor finding: heap overflow from a resize to the old B and a draw with the new one): every thread gets
+  exactly the indices and final state of the plain draw."""
+  import threading
+  specs = [(7, 200_003, 64, 40), (8, 90_001, 2048, 40), (9, 333_337, 16, 40)]
+  res = {}
+
+  def run(i, seed, n, B, calls):
+    res[i] = _ahead_stream(seed, n, B, calls, n)
+
+  ths = [threading.Thread(target=run, args=(i,) + sp) for i, sp in enumerate(specs)]
+  for t in ths:
+    t.start()
+  for t in ths:
+    t.join(timeout=120)
+    assert not t.is_alive()
+  for i, (seed, n, B, calls) in enumerate(specs):
+    exp, mt, pos = _direct_stream(seed, n, B, calls)
+    got, gmt, gpos = res[i]
+    for a, b in zip(got, exp):
+      np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(gmt, mt)
+    assert gpos == pos
+
+
+def test_sampler_ahead_of_time_survives_fork():
+  """The helper thread does not exist in a fork()ed child (a DataLoader worker, multiprocessing's fork start method);
+  the child must start its own instead of waiting for the parent's (round-2 advisor finding: second call blocks)."""
+  import os
+  import signal
+  _ahead_stream(1, 50_000, 32, 3, 50_000)      # the parent's worker thread exists and has a speculation posted
+  exp, _, pos = _direct_stream(2, 60_000, 24, 4)
+  r, w = os.pipe()
+  pid = os.fork()
+  if pid == 0:      # child: no pytest machinery, just the calls
+    ok = b'0'
+    try:
+      signal.alarm(30)      # a blocked child dies instead of hanging the suite
+      got, _, gpos = _ahead_stream(2, 60_000, 24, 4, 60_000)
+      ok = b'1' if all(np.array_equal(a, b) for a, b in zip(got, exp)) and gpos == pos else b'2'
+    finally:
+      os.write(w, ok)
+      os._exit(0)
+  os.close(w)
+  _, status = os.waitpid(pid, 0)
+  assert os.read(r, 1) == b'1', status
+  os.close(r)
+  # and the parent's worker still serves the parent
+  got, _, _ = _ahead_stream(2, 60_000, 24, 4, 60_000)
+  for a, b in zip(got, exp):
+    np.testing.assert_array_equal(a, b)

@@ -204,6 +204,23 @@ def test_ddpg_one_launch_chain_state_is_per_stream_and_shared_by_learners():
     _lib.lib().trl_offpolicy_set_chain(1)
 
 
+def test_ddpg_chain_barrier_timeout_is_reported():
+  """The one-launch chain's device-wide barrier needs every workgroup resident; when one is not (here: the diagnostic
+  build withholds one), the bounded wait must end in an ERROR at the next call on the stream -- not in silently wrong
+  weights -- and the steps after it must be right again.  Runs in a child process on lib/libtrl_hip_tune.so
+  (tests/chain_fault_child.py has the assertions)."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  if not os.path.exists(os.path.join(root, 'torchrl_amd', 'lib', 'libtrl_hip_tune.so')):
+    pytest.skip('diagnostic build not present')
+  env = dict(os.environ, TRL_LIB='tune', TRL_CHAIN_WITHHOLD='3', TRL_CHAIN_SPIN='4000', PYTHONPATH=root)
+  r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'chain_fault_child.py')], env=env, capture_output=True,
+                     text=True, timeout=110)
+  assert r.returncode == 0 and 'chain fault child ok' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 DQN_SHAPES = [(4, 2, 128, 256), (4, 2, 128, 32), (8, 6, (64, 32), 48), (33, 18, (256, 128), 128)]
 
 

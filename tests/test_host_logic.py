@@ -275,3 +275,22 @@ def test_bench_is_a_rank_under_torch_distributed_run(monkeypatch):
   with pytest.raises(KeyboardInterrupt):
     bench.main(['--gpus', '2'])
   assert 'launched' not in called
+
+
+def test_act_rng_streams_differ_per_instance_and_rank():
+  """Default-seeded on-device exploration streams: two controllers of one process, and the same controller on two
+  data-parallel ranks seeded alike, must get different Philox keys (round-2 advisor finding); an explicit seed is
+  used as given, and a stream is reproducible from (torch seed, instance order, rank)."""
+  from torchrl_amd import functional as F
+  torch.manual_seed(123)
+  a, b = F.ActRng(), F.ActRng()
+  sa, sb = a.next(), b.next()
+  assert sa[0] != sb[0] and sa[1] == sb[1] == 0
+  assert a.next() == (sa[0], 1)
+  r0, r1 = F.ActRng(rank=0), F.ActRng(rank=1)
+  r1._instance = r0._instance      # the same controller, constructed in the same order, on two ranks
+  assert r0.next()[0] != r1.next()[0]
+  assert F.ActRng(7).next() == (7, 0) and F.ActRng(7).next() == (7, 0)
+  x, y = F.ActRng(rank=0), F.ActRng(rank=0)
+  y._instance = x._instance
+  assert x.next() == y.next()

@@ -114,9 +114,10 @@ class DDPGController(Controller):
     with torch.no_grad():
       action = self.actor(obs)
       if getattr(self, '_ou_dev', None) is None:
-        self._ou_dev = [torch.empty(noise.action_dim, device=self.device) for _ in range(2)]
+        # the process carries on from wherever act() has taken it: same state, same place in the sigma / reset schedule
+        self._ou_dev = [torch.as_tensor(np.asarray(noise.state, dtype=np.float32), device=self.device).clone()
+                        for _ in range(2)]
         self._ou_cur = 0
-        noise.step = 0
       if noise.step == 0:                         # fresh or just reset: the state starts at mu (OUNoise.reset)
         self._ou_dev[self._ou_cur].fill_(float(noise.mu))
       src, dst = self._ou_dev[self._ou_cur], self._ou_dev[1 - self._ou_cur]

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void k_rollout_push(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------- exploration
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
+// 23 random bits + one half: k + 0.5 is exact for every k < 2^23 (24 significant bits), so the value is strictly inside
+// (0, 1) -- with 24 bits the half was rounded away for k >= 2^23 and k = 2^24 - 1 gave exactly 1.0
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 // two independent standard normals from 64 random bits (Box-Muller)
 __device__ __forceinline__ void normal2(uint64_t bits, float *z0, float *z1) {
@@ -97,13 +99,16 @@ __global__ __launch_bounds__(256) void k_act_categorical(const float *__restrict
     float s = 0.f;
     for (int a = 0; a < A; ++a) s += row[a];
     const float u = u01((uint32_t)(philox64(seed, call, (uint32_t)b, (uint32_t)(b >> 32)) >> 32)) * s;
+    // (u < s always in exact arithmetic; if the running sum's rounding leaves u >= acc to the end, the pick is the
+    // last action that HAS probability, never a zero-probability one)
     float acc = 0.f;
-    int pick = A - 1;
+    int pick = -1, last = 0;
     for (int a = 0; a < A; ++a) {
+      if (row[a] > 0.f) last = a;
       acc += row[a];
-      if (u < acc) { pick = a; break; }
+      if (pick < 0 && u < acc && row[a] > 0.f) pick = a;
     }
-    out[b] = pick;
+    out[b] = pick < 0 ? last : pick;
   }
 }
 

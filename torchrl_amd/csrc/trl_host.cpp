@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
+#include <new>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -454,35 +456,53 @@ struct Worker {
   std::condition_variable cv;
   Job job;
   State state = IDLE;
-  bool quit = false, started = false;
-  std::thread th;
+  bool started = false;
   void loop() {
     std::unique_lock<std::mutex> lk(mu);
+    std::vector<int64_t> idx;
+    uint32_t st[MT_N];
     for (;;) {
-      cv.wait(lk, [&] { return state == PENDING || quit; });
-      if (quit) return;
+      cv.wait(lk, [&] { return state == PENDING; });
       state = RUNNING;
+      // the job's inputs are taken under the lock; while RUNNING nobody posts (callers post only into an IDLE worker)
+      const int64_t n = job.n, B = job.B;
+      int32_t left = job.left_in, next = job.next_in;
+      memcpy(st, job.mt_in, sizeof(st));
       lk.unlock();
-      memcpy(job.mt_out, job.mt_in, sizeof(job.mt_in));
-      job.left_out = job.left_in;
-      job.next_out = job.next_in;
-      job.idx.resize((size_t)job.B);
-      job.rc = randperm_prefix_impl(job.mt_out, &job.left_out, &job.next_out, job.n, job.B, job.idx.data(), true);
+      idx.resize((size_t)B);
+      const int rc = randperm_prefix_impl(st, &left, &next, n, B, idx.data(), true);
       lk.lock();
+      memcpy(job.mt_out, st, sizeof(st));
+      job.left_out = left;
+      job.next_out = next;
+      job.idx.swap(idx);
+      job.rc = rc;
       state = DONE;
       cv.notify_all();
     }
   }
-  ~Worker() {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      quit = true;
-    }
-    cv.notify_all();
-    if (th.joinable()) th.join();
-  }
 };
-Worker g_worker;
+// The worker is created on first use and never destroyed (its thread ends with the process).  A fork()ed child has the
+// object but not the thread: the child gets a fresh, unstarted worker (pthread_atfork), so its first call starts its own
+// thread instead of waiting for a job that nobody runs.
+Worker *g_worker = nullptr;
+std::mutex g_worker_mu;
+void after_fork_in_child() {
+  g_worker = nullptr;                 // (the parent's object is leaked in the child: its mutex may be held by a thread
+  new (&g_worker_mu) std::mutex();    //  that does not exist here)
+}
+Worker &worker() {
+  std::lock_guard<std::mutex> lk(g_worker_mu);
+  if (!g_worker) {
+    static bool hooked = false;
+    if (!hooked) {
+      pthread_atfork(nullptr, nullptr, after_fork_in_child);
+      hooked = true;
+    }
+    g_worker = new Worker();
+  }
+  return *g_worker;
+}
 }  // namespace spec
 
 extern "C" int trl_randperm_prefix_ahead(uint32_t *mt, int32_t *left, int32_t *next, int64_t n, int64_t B,
@@ -492,20 +512,29 @@ extern "C" int trl_randperm_prefix_ahead(uint32_t *mt, int32_t *left, int32_t *n
     trl_set_error("trl_randperm_prefix_ahead: null argument");
     return TRL_EINVAL;
   }
-  Worker &w = g_worker;
+  Worker &w = worker();
   bool matched = false;
   {
+    // A finished speculation that matches this call's generator state is consumed; one that is still being computed
+    // is waited for only if it was started FROM this state (then its result is what this call needs); anything else
+    // -- another thread's speculation, a stale one -- is left alone and this call computes on its own thread.
     std::unique_lock<std::mutex> lk(w.mu);
-    w.cv.wait(lk, [&] { return w.state == IDLE || w.state == DONE; });     // (a running speculation is seconds at most)
-    if (w.state == DONE && w.job.rc == TRL_OK && w.job.n == n && w.job.B == B && w.job.left_in == *left &&
-        w.job.next_in == *next && memcmp(w.job.mt_in, mt, sizeof(w.job.mt_in)) == 0) {
-      memcpy(mt, w.job.mt_out, sizeof(w.job.mt_out));
-      *left = w.job.left_out;
-      *next = w.job.next_out;
-      if (B > 0) memcpy(out_h, w.job.idx.data(), (size_t)B * sizeof(int64_t));
-      matched = true;
+    auto same_input = [&] {
+      return w.job.n == n && w.job.B == B && w.job.left_in == *left && w.job.next_in == *next &&
+             memcmp(w.job.mt_in, mt, sizeof(w.job.mt_in)) == 0;
+    };
+    if ((w.state == PENDING || w.state == RUNNING) && same_input())
+      w.cv.wait(lk, [&] { return w.state == DONE || w.state == IDLE; });
+    if (w.state == DONE && same_input()) {
+      if (w.job.rc == TRL_OK) {
+        memcpy(mt, w.job.mt_out, sizeof(w.job.mt_out));
+        *left = w.job.left_out;
+        *next = w.job.next_out;
+        if (B > 0) memcpy(out_h, w.job.idx.data(), (size_t)B * sizeof(int64_t));
+        matched = true;
+      }
+      w.state = IDLE;
     }
-    w.state = IDLE;
   }
   if (!matched) {
     const int rc = randperm_prefix_impl(mt, left, next, n, B, out_h, true);
@@ -514,17 +543,22 @@ extern "C" int trl_randperm_prefix_ahead(uint32_t *mt, int32_t *left, int32_t *n
   if (hit) *hit = matched ? 1 : 0;
   if (next_n > 0 && B <= next_n) {
     std::lock_guard<std::mutex> lk(w.mu);
-    if (!w.started) {
-      w.th = std::thread([&w] { w.loop(); });
-      w.started = true;
+    // post only into a worker that holds nothing in flight: a pending / running job belongs to another caller (its
+    // inputs must not change under the worker), and then this call simply does not speculate.  A DONE result that
+    // nobody has taken is stale by now (its consumer would have matched above) and is overwritten.
+    if (w.state == IDLE || w.state == DONE) {
+      if (!w.started) {
+        std::thread([&w] { w.loop(); }).detach();
+        w.started = true;
+      }
+      memcpy(w.job.mt_in, mt, sizeof(w.job.mt_in));
+      w.job.left_in = *left;
+      w.job.next_in = *next;
+      w.job.n = next_n;
+      w.job.B = B;
+      w.state = PENDING;
+      w.cv.notify_all();
     }
-    memcpy(w.job.mt_in, mt, sizeof(w.job.mt_in));
-    w.job.left_in = *left;
-    w.job.next_in = *next;
-    w.job.n = next_n;
-    w.job.B = B;
-    w.state = PENDING;
-    w.cv.notify_all();
   }
   return TRL_OK;
 }

@@ -494,41 +494,74 @@ __global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
 // y = reward + (1 - done) * gamma * next_q;  critic loss = mean(l(cur - y));  actor loss = -mean(q_pi)
 // (ddpg_controller.py:105-112), and the gradient of the critic loss at cur.  One workgroup.
 // ---- the whole chain in ONE launch: every workgroup walks the phases, taking the tiles wg, wg + gridDim.x, ... of each,
-// with a device-wide barrier between two phases.  All workgroups are resident (the host launches at most two per CU),
-// the waits are bounded (a launch that lost a workgroup ends with wrong numbers rather than hanging the GPU).
-// bar (32-dword lines): line 0 the arrival count, line 1 the generation.
-__device__ __forceinline__ void chain_barrier(unsigned *bar, unsigned &gen, int nsleep) {
+// with a device-wide barrier between two phases.  The barrier needs every workgroup resident at once: the host sizes the
+// grid from the occupancy the runtime reports for this kernel, but another process or stream on the card can still
+// take the CUs away, so every wait is bounded AND a wait that runs out is reported, never passed over: the workgroup
+// raises the launch's abort flag (which the polling workgroups, and workgroups that only start now, see and leave on),
+// writes 1 + the phase index to a pinned host word and NaN to the step's losses; the host finds the word at its next
+// call on the stream, clears the barrier block, returns TRL_EHIP and runs that stream's later steps as launches.
+// bar (32-dword lines): line 0 the arrival count, line 1 the generation word; the generation word holding CHAIN_POISON
+// IS the abort flag, so the polls see it for free and the workgroup that arrives last cannot complete a barrier the
+// others have given up on (it publishes the new generation by compare-and-swap from the old one).
+constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 20;      // polls of ~1.5 us: about 1.5 s (a phase is under 10 us)
+constexpr unsigned CHAIN_POISON = 0xFFFFFFFFu;
+
+// returns false when the launch is aborted (this workgroup's wait ran out, or another's did)
+__device__ __forceinline__ bool chain_barrier(unsigned *bar, unsigned &gen, int nsleep, unsigned spin_limit,
+                                              unsigned *fault_h, int phase, int *ok_lds) {
   __builtin_amdgcn_s_waitcnt(0);     // this thread's write-through stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned want = gen + 1;
+    unsigned want = gen + 1;
+    if (want == CHAIN_POISON) want = 0;     // (every workgroup passes every barrier, so equality is the test and wrapping is harmless)
+    int ok = 0;
     if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_s_waitcnt(0);
-      __hip_atomic_store(bar + 32, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned expect = gen;
+      ok = __hip_atomic_compare_exchange_strong(bar + 32, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;      // fails only on the poison
     } else {
-      for (int spin = 0; spin < (1 << 22); ++spin) {
-        if ((int)(__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+      bool poisoned = false;
+      for (unsigned spin = 0; spin < spin_limit; ++spin) {
+        const unsigned v = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == want) { ok = 1; break; }
+        if (v == CHAIN_POISON) { poisoned = true; break; }
         for (int j = 0; j < nsleep; ++j) __builtin_amdgcn_s_sleep(4);     // (polls of idle workgroups slow the busy ones)
+      }
+      if (!ok && !poisoned) {      // this workgroup's wait ran out: abort the launch, tell the host (the first one's phase stays)
+        if (__hip_atomic_exchange(bar + 32, CHAIN_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CHAIN_POISON)
+          __hip_atomic_store(fault_h, (unsigned)(1 + phase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     gen = want;
+    *ok_lds = ok;
   }
   __syncthreads();
+  return *ok_lds != 0;
 }
 
 constexpr int MAX_PHASES = 12;
 
-__global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ table, int nphase, unsigned *bar, int nsleep) {
+__global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ table, int nphase, unsigned *bar, int nsleep,
+                                               unsigned spin_limit, unsigned *fault_h, int flags) {
   __shared__ float red[4][256];
   __shared__ __align__(16) int tab[MAX_PHASES * (sizeof(PhaseArgs) / 4)];
+  __shared__ int ok_lds;
   static_assert(sizeof(PhaseArgs) % 4 == 0, "dword copy");
   constexpr int PW = sizeof(PhaseArgs) / 4;
+#ifdef TRL_TUNING      // diagnostic build: the last workgroup never arrives (the test of the barrier's time-out path)
+  if ((flags & 1) && blockIdx.x == gridDim.x - 1 && gridDim.x > 1) return;
+#endif
   // the phase table (pinned host memory, written by the host for this launch) -> LDS, one round trip
   for (int e = threadIdx.x; e < nphase * PW; e += 256) tab[e] = ((const int *)table)[e];
   unsigned gen = 0;
-  if (threadIdx.x == 0) gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok_lds = gen == CHAIN_POISON ? 0 : 1;    // an earlier launch on this stream was aborted and the host has not yet
+  }                                          // cleared the block: do nothing (the host reports it at its next call)
   __syncthreads();
+  if (!ok_lds) return;
   for (int p = 0; p < nphase; ++p) {
 #ifdef TRL_TUNING      // diagnostic build: 100 MHz stamps of workgroup 0 at each phase's start and at its barrier
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -568,7 +601,18 @@ __global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ tab
 #ifdef TRL_TUNING
     if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long *)(bar + 64))[2 * p + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (p + 1 < nphase) chain_barrier(bar, gen, nsleep);
+    if (p + 1 < nphase && !chain_barrier(bar, gen, nsleep, spin_limit, fault_h, p, &ok_lds)) {
+      // aborted: no further phase runs (no further update is applied); the step's loss values say so
+      if (threadIdx.x == 0)
+        for (int q = 0; q < nphase; ++q) {
+          const PhaseArgs &Q = *(const PhaseArgs *)(tab + q * PW);
+          if (Q.sum_extra && Q.L.losses_out) {
+            Q.L.losses_out[0] = __builtin_nanf("");
+            Q.L.losses_out[1] = __builtin_nanf("");
+          }
+        }
+      return;
+    }
   }
 #ifdef TRL_TUNING
   if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long *)(bar + 64))[2 * nphase] = __builtin_amdgcn_s_memrealtime();
@@ -642,7 +686,9 @@ struct ChainState {
   hipEvent_t ev[CHAIN_SLOTS];
   bool used[CHAIN_SLOTS];
   uint64_t n = 0;
-  int max_wgs = 0;                  // resident-workgroup budget of the device: two per CU
+  int max_wgs = 0;                  // resident-workgroup budget: what the runtime says fits of k_chain, at most two per CU
+  unsigned *fault_h = nullptr;      // pinned host word: 0, or 1 + the phase whose barrier timed out (written by the kernel)
+  bool launches_only = false;       // after a reported time-out this stream's steps run as one launch per phase
 };
 std::mutex g_chain_mu;
 std::unordered_map<uint64_t, ChainState *> g_chains;     // key: stream handle ^ (device << 56)
@@ -660,10 +706,14 @@ ChainState *chain_state(const char *fn, hipStream_t st) {
   auto it = g_chains.find(key);
   if (it != g_chains.end()) return it->second;
   ChainState *c = new ChainState();
+  int per_cu = 0;      // workgroups of k_chain (256 threads, its static LDS, its registers) the runtime says fit on one CU
   bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain, 256, 0) == hipSuccess &&
             hipMalloc((void **)&c->bar, 256 * sizeof(unsigned)) == hipSuccess &&
             hipMemset(c->bar, 0, 256 * sizeof(unsigned)) == hipSuccess &&
-            hipHostMalloc((void **)&c->tables, sizeof(PhaseArgs) * CHAIN_SLOTS * MAX_PHASES, hipHostMallocDefault) == hipSuccess;
+            hipHostMalloc((void **)&c->tables, sizeof(PhaseArgs) * CHAIN_SLOTS * MAX_PHASES, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void **)&c->fault_h, 64, hipHostMallocDefault) == hipSuccess;
+  if (ok) *(volatile unsigned *)c->fault_h = 0u;
   for (int i = 0; ok && i < CHAIN_SLOTS; ++i) {
     ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
     c->used[i] = false;
@@ -674,7 +724,7 @@ ChainState *chain_state(const char *fn, hipStream_t st) {
     delete c;
     return nullptr;
   }
-  c->max_wgs = 2 * cus;
+  c->max_wgs = (per_cu < 2 ? per_cu : 2) * cus;      // 0: the kernel does not fit at all -> launches (run_chain)
   g_chains[key] = c;
   return c;
 }
@@ -705,6 +755,19 @@ int run_chain(const Chain &c, hipStream_t st, const char *what) {
   TRL_REQUIRE(!c.full, "%s: internal: more than %d phases", what, MAX_PHASES);
   ChainState *cs = chain_state(what, st);
   if (!cs) return TRL_EHIP;
+  if (const unsigned f = *(volatile unsigned *)cs->fault_h) {
+    // a launch of the chain on this stream gave up at a barrier (a workgroup was not resident: the card is shared, or
+    // the occupancy estimate was wrong).  That step -- and any step queued behind it, which did nothing -- is lost; say
+    // so, clean the barrier block behind them on the stream, and keep to one launch per phase on this stream from now on.
+    *(volatile unsigned *)cs->fault_h = 0u;
+    cs->launches_only = true;
+    if (hipMemsetAsync(cs->bar, 0, 256 * sizeof(unsigned), st) != hipSuccess) (void)hipGetLastError();
+    trl_set_error("%s: an earlier one-launch step on this stream timed out at the device-wide barrier after phase %u (not "
+                  "every workgroup was resident); its losses are NaN, its update is incomplete and steps queued behind it "
+                  "did not run.  This stream now runs the step as one launch per phase", what, f - 1u);
+    return TRL_EHIP;
+  }
+  if (cs->launches_only || cs->max_wgs < 1) return run_launches(c, st, what);
   const int slot = (int)(cs->n++ % CHAIN_SLOTS);
   if (cs->used[slot] && hipEventSynchronize(cs->ev[slot]) != hipSuccess) {    // (16 launches back: long finished)
     trl_set_error("%s: waiting for an earlier launch of the chain failed", what);
@@ -718,11 +781,17 @@ int run_chain(const Chain &c, hipStream_t st, const char *what) {
 #ifdef TRL_TUNING
   if (const char *e = getenv("TRL_CHAIN_WGS")) wgs = atoi(e) < wgs ? atoi(e) : wgs;     // A/B runs of tools/ only
 #endif
-  int nsleep = 2;
+  int nsleep = 2, flags = 0;
+  unsigned spin_limit = CHAIN_SPIN_LIMIT;
 #ifdef TRL_TUNING
   if (const char *e = getenv("TRL_CHAIN_SLEEP")) nsleep = atoi(e);
+  if (const char *e = getenv("TRL_CHAIN_SPIN")) spin_limit = (unsigned)atoi(e);
+  if (const char *e = getenv("TRL_CHAIN_WITHHOLD")) {      // the n-th chain launch of the stream loses a workgroup (n = value)
+    if ((uint64_t)atoll(e) == cs->n) flags |= 1;
+  }
 #endif
-  hipLaunchKernelGGL(k_chain, dim3(wgs), dim3(256), 0, st, (const PhaseArgs *)tab, c.n, cs->bar, nsleep);
+  hipLaunchKernelGGL(k_chain, dim3(wgs), dim3(256), 0, st, (const PhaseArgs *)tab, c.n, cs->bar, nsleep, spin_limit,
+                     cs->fault_h, flags);
   TRL_CHECK_LAUNCH(what);
   if (hipEventRecord(cs->ev[slot], st) != hipSuccess) {
     trl_set_error("%s: hipEventRecord failed", what);

@@ -152,14 +152,33 @@ def from_blocked(x):
 # ------------------------------------------------------------------------------ exploration on the device
 class ActRng:
   """Seed + call counter of a controller's on-device exploration (csrc/trl_act.hip: Philox keyed by the seed,
-  counter = (call number, row)); the seed defaults to torch.initial_seed() at the first draw."""
+  counter = (call number, row)); the seed defaults to torch.initial_seed() at the first draw, mixed with a stream id
+  that is different for every ActRng of the process and for every rank of a data-parallel job -- two agents, or N
+  ranks seeded alike, must not explore in lock-step (the reference's consumers draw one after the other from one
+  numpy generator and so never see the same numbers either).  An explicit `seed` is used as given."""
+  _instances = 0
 
-  def __init__(self, seed=None):
+  def __init__(self, seed=None, rank=None):
     self.seed, self.calls = seed, 0
+    self._rank = rank
+    self._instance = ActRng._instances
+    ActRng._instances += 1
+
+  @staticmethod
+  def _mix(x):      # splitmix64 finalizer: distinct inputs -> well-separated Philox keys
+    m = 2 ** 64 - 1
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
 
   def next(self):
     if self.seed is None:
-      self.seed = int(torch.initial_seed())
+      rank = self._rank
+      if rank is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+      self.seed = self._mix(int(torch.initial_seed()) ^ self._mix((rank << 32) | self._instance))
     self.calls += 1
     return self.seed & (2 ** 64 - 1), self.calls - 1
 
