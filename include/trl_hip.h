@@ -386,6 +386,32 @@ int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor,
                           const float *obs, const float *action, int64_t B, int32_t A, float *value, float *mean,
                           float *logp, void *stream);
 
+/* The reference's PPO minibatch loop in ONE launch: `for epoch in range(n_epochs): for minibatch in loader:
+ * controller.learn(*minibatch)` (examples/ppo.py:66-73 over ppo_controller.py:53-80), i.e. K = n_epochs *
+ * ceil(n_rows / minibatch) consecutive learn() steps -- forward, clipped-surrogate / value / entropy loss, backward,
+ * clip_grad_value_, Adam -- each on the weights the step before it left.  The minibatches are the consecutive row
+ * ranges [j * minibatch, (j + 1) * minibatch) of the columns, the last one of an epoch short if n_rows is not a
+ * multiple (DataLoader's shuffle=False, drop_last=False, ppo.py:68).  At the reference's minibatch sizes (32 / 64) a
+ * step is a few microseconds of dependent arithmetic, so the loop runs as two persistent workgroups (the critic's
+ * and the actor's chains of updates are independent) with parameters and Adam moments resident on the CU between
+ * updates (csrc/trl_epoch.hip).
+ *   critic, actor: depth 2 (one hidden layer, a multiple of 16 up to 256) or depth 3 (two hidden layers, multiples of
+ *   16 up to 64), same fan-in <= 15; critic fan-out 1, actor fan-out A (1 <= A <= 4); log_std [A].  All parameters
+ *   must lie inside adam->param (the flat buffer); moments at the same offsets of adam->exp_avg / exp_avg_sq.
+ *   obs [n_rows, fan-in]; action, old_logp [n_rows, A]; returns, adv [n_rows].  1 <= minibatch <= 4096.
+ *   adam: required; adam->step = the 1-based count of the FIRST update (the caller advances its count by K);
+ *   clip_value as in trl_adam_step; grad_scale must be 1, dev_state NULL (single rank, eager).
+ *   losses_out [K][4] = actor, critic, entropy, actor + alpha * critic - beta * entropy of every step, in order.
+ *   On return (stream order) param / exp_avg / exp_avg_sq hold the state after K updates and adam->grad the clipped
+ *   gradients of the last one, as K calls of trl_ppo_learn_fused(..., adam) would leave them -- the same arithmetic
+ *   (exact f32 products, torch's Adam op order) up to the order of the f32 sums.
+ * `ws`: trl_ppo_learn_epoch_workspace_bytes() bytes of device scratch (the K steps' bias corrections). */
+int64_t trl_ppo_learn_epoch_workspace_bytes(int64_t n_rows, int64_t minibatch, int32_t n_epochs);
+int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std, const float *obs,
+                        const float *action, const float *returns, const float *old_logp, const float *adv,
+                        int64_t n_rows, int64_t minibatch, int32_t n_epochs, int32_t A, double clip, double alpha,
+                        double beta, float *losses_out, const trl_adam_args *adam, void *ws, void *stream);
+
 /* ------------------------------------------------------------------ fused off-policy learner steps (a-2 + a-4)
  * DDPGController.learn (ddpg_controller.py:101-128) as 10 phases of one tile kernel (csrc/trl_offpolicy.hip;
  * one launch, or one per phase: trl_offpolicy_set_chain): the five

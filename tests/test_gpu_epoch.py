@@ -1,0 +1,185 @@
+"""The reference's PPO minibatch loop as one launch (csrc/trl_epoch.hip, C ABI trl_ppo_learn_epoch, PPOController.learn_epoch)
+against (1) the oracle's torch-CPU restatement of the loop `for minibatch in loader: controller.learn(*minibatch)`
+(examples/ppo.py:66-73 over ppo_controller.py:53-80; oracle/loss_oracle.py is pinned to the reference by
+tests/golden/ppo.npz), (2) the same number of consecutive PPOController.learn() calls on the GPU, and (3) the
+reference's own two-step outputs in tests/golden/ppo.npz.
+
+Bars: the first step's losses 1e-6 relative (+ 2e-7 absolute for terms near 0) -- identical inputs; later steps see
+weights that differ from the yardstick's by f32 summation order amplified by Adam (a round-off-sized difference of a
+near-zero gradient is an lr-sized move: the bar tests/test_gpu_learn.py documents for one step), so their losses are held
+to 2e-5 relative and the final weights to `steps x 2.5 lr` everywhere, with fewer than 2 % of them further than 2e-5
+off."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle
+from torchrl_amd.contrib.controllers import PPOController
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+LR = 3e-4
+
+
+def _data(obs_size, A, n, seed, net):
+  g = torch.Generator().manual_seed(seed)
+  obs = torch.randn(n, obs_size, generator=g)
+  act = torch.randn(n, A, generator=g)
+  ret = torch.randn(n, 1, generator=g)
+  adv = torch.randn(n, 1, generator=g)
+  with torch.no_grad():
+    mean = net.actor(obs)
+    old = torch.distributions.Normal(mean, net.log_std.exp().expand_as(mean)).log_prob(act)
+    old = old + 0.3 * torch.randn(n, A, generator=g)        # ratios on both sides of the clip range
+  return obs, act, ret, old, adv
+
+
+def _make(obs_size, A, hidden, seed, max_grad_norm=0.05):
+  torch.manual_seed(seed)
+  ctl = PPOController(obs_size, A, lr=LR, alpha=0.5, beta=1e-2, clip_ratio=0.2, max_grad_norm=max_grad_norm,
+                      device=DEV, hidden=hidden)
+  with torch.no_grad():
+    ctl.ac_net.log_std.add_(torch.linspace(-0.3, 0.2, A, device=DEV).view(1, A))
+  return ctl
+
+
+def _cols(obs, act, ret, old, adv):
+  d = lambda t: t.to(DEV)
+  return [d(obs), d(act), None, None, None, d(ret), d(old), d(adv)]
+
+
+# obs size, actions, hidden, minibatch, rows, epochs
+CASES = [(3, 1, (64, 64), 64, 64 * 6, 1),          # the BASELINE network at the reference's spec minibatch
+         (3, 1, (256,), 64, 64 * 5 + 17, 1),       # the reference's own network (ppo_controller.py:14), short last minibatch
+         (3, 1, (256,), 32, 32 * 4, 2),            # the reference's default minibatch, two epochs
+         (4, 2, (64, 64), 32, 200, 1),
+         (8, 4, (128,), 48, 48 * 4 + 5, 1),
+         (15, 1, (32, 16), 100, 350, 1),           # minibatch > one 64-sample tile; widest fan-in
+         (3, 2, (256,), 200, 500, 1),
+         (2, 2, (16,), 7, 30, 2),
+         (1, 3, (48, 64), 64, 128, 1)]
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B,n,epochs', CASES)
+def test_learn_epoch_matches_the_oracle_loop(obs_size, A, hidden, B, n, epochs):
+  ctl = _make(obs_size, A, hidden, obs_size + 10 * A + B)
+  assert ctl._epoch is not None
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  ref_opt = torch.optim.Adam(ref.parameters(), lr=LR)
+  obs, act, ret, old, adv = _data(obs_size, A, n, 7 + B, ref)
+  exp = []
+  for _ in range(epochs):
+    for s in range(0, n, B):
+      e = min(n, s + B)
+      exp.append(loss_oracle.ppo_learn(ref, ref_opt, obs[s:e], act[s:e], None, None, None, ret[s:e], old[s:e], adv[s:e],
+                                       clip=0.2, alpha=0.5, beta=1e-2, max_grad_norm=0.05))
+  exp_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])      # the last step's, after clip_grad_value_
+  K = len(exp)
+  got = ctl.learn_epoch(_cols(obs, act, ret, old, adv), B, epochs)
+  torch.cuda.synchronize()
+  assert ctl.ac_net_optim.step_count == K
+  for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+    assert got[k].shape == (K,)
+    for j in range(K):
+      e, v = float(exp[j][k]), float(got[k][j].cpu())
+      tol = 1e-6 if j == 0 else 2e-5
+      assert abs(v - e) <= tol * abs(e) + 2e-7 * (1 if j == 0 else 5), (k, j, v, e)
+  exp_w = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+  got_w = ctl._flat.dense().cpu()
+  d = (got_w - exp_w).abs()
+  assert float(d.max()) <= 2.5 * LR * K, float(d.max())
+  assert float((d > 2e-5).float().mean()) < 0.02, float((d > 2e-5).float().mean())
+  got_grad = ctl._flat.dense(grad=True).cpu()
+  scale = float(exp_grad.abs().max())
+  close = ((got_grad - exp_grad).abs() <= 1e-3 * exp_grad.abs() + 1e-4 * scale).float().mean()
+  assert float(close) > 0.98, float(close)      # (the last step's gradients, taken at slightly different weights)
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B,n,epochs', [(3, 1, (64, 64), 64, 64 * 8, 1), (3, 1, (256,), 64, 64 * 8, 2),
+                                                          (4, 2, (64, 64), 32, 32 * 5 + 32, 1)])
+def test_learn_epoch_equals_consecutive_learn_calls(obs_size, A, hidden, B, n, epochs):
+  """K learn() calls (two launches each: the whole-step kernel + reduce / Adam) against ONE learn_epoch launch: the same
+  arithmetic in another summation order.  First step's losses 1e-6, moments and weights as above."""
+  a, b = _make(obs_size, A, hidden, 5), _make(obs_size, A, hidden, 5)
+  assert torch.equal(a._flat.data, b._flat.data)
+  obs, act, ret, old, adv = _data(obs_size, A, n, 3, copy.deepcopy(a.ac_net).cpu())
+  cols = _cols(obs, act, ret, old, adv)
+  got = a.learn_epoch(cols, B, epochs)
+  seq = dict(actor_loss=[], critic_loss=[], entropy_loss=[])
+  for _ in range(epochs):
+    for s in range(0, n, B):
+      info = b.learn(*[c[s:s + B] if c is not None else None for c in cols])
+      for k in seq:
+        seq[k].append(float(info[k]))
+  torch.cuda.synchronize()
+  K = len(seq['actor_loss'])
+  assert a.ac_net_optim.step_count == b.ac_net_optim.step_count == K
+  for k in seq:
+    for j in range(K):
+      e, v = seq[k][j], float(got[k][j])
+      assert abs(v - e) <= (1e-6 if j == 0 else 2e-5) * abs(e) + 2e-7 * (1 if j == 0 else 5), (k, j, v, e)
+  d = (a._flat.data - b._flat.data).abs()
+  assert float(d.max()) <= 2.5 * LR * K
+  assert float((d > 2e-5).float().mean()) < 0.02
+  dm = (a.ac_net_optim.exp_avg - b.ac_net_optim.exp_avg).abs()
+  assert float(dm.max()) <= 1e-3 * float(b.ac_net_optim.exp_avg.abs().max()) + 1e-6
+
+
+def test_learn_epoch_golden_reference_two_steps(golden):
+  """tests/golden/ppo.npz: two consecutive learn() steps of the REFERENCE's PPOController on ActorCriticNet(3, A, 256).
+  Where both steps' batches have the same size they are one learn_epoch call (minibatch = that size): both steps'
+  losses, the second step's clipped gradients and the weights after it, at the fixtures' bars."""
+  g = golden('ppo.npz')
+  from tests.helpers import FIELDS, state_from, t
+  ran = 0
+  for ci in range(int(g['n_ppo'])):
+    p = 'ppo%d_' % ci
+    A = g[p + 'net0.log_std'].shape[1]
+    names = FIELDS + ('returns', 'old_log_probs', 'advantages')
+    steps = [[t(g['%sstep%d_%s' % (p, s, f)], DEV) for f in names] for s in range(2)]
+    if steps[0][0].shape[0] != steps[1][0].shape[0] or A > 4:
+      continue
+    c = PPOController(3, A, lr=3e-4, alpha=0.5, beta=float(g[p + 'beta']), clip_ratio=0.2,
+                      max_grad_norm=float(g[p + 'max_grad_norm']), device=DEV)
+    c.ac_net.load_state_dict(state_from(g, p + 'net0'))
+    assert c._epoch is not None
+    B = steps[0][0].shape[0]
+    cols = [torch.cat([steps[0][i], steps[1][i]], 0) for i in range(8)]
+    info = c.learn_epoch(cols, B, 1)
+    for s in range(2):
+      for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+        np.testing.assert_allclose(float(info[k][s].cpu()), float(g['%sstep%d_%s' % (p, s, k)]), rtol=1e-6 if s == 0 else 1e-5,
+                                   atol=2e-7)
+    exp_g, exp_w = np.asarray(g['%sstep1_grad' % p]), np.asarray(g['%sstep1_net' % p])
+    np.testing.assert_allclose(c._flat.dense(grad=True).cpu().numpy(), exp_g, rtol=1e-3, atol=1e-4 * float(np.abs(exp_g).max()))
+    np.testing.assert_allclose(c._flat.dense().cpu().numpy(), exp_w, rtol=1e-5, atol=1e-5 * float(np.abs(exp_w).max()) + 2.5 * 3e-4)
+    ran += 1
+  assert ran >= 1
+
+
+def test_learn_epoch_is_reproducible_and_falls_back():
+  ctl = _make(3, 1, (64, 64), 1)
+  obs, act, ret, old, adv = _data(3, 1, 300, 2, copy.deepcopy(ctl.ac_net).cpu())
+  cols = _cols(obs, act, ret, old, adv)
+  outs = []
+  for _ in range(2):
+    c = _make(3, 1, (64, 64), 1)
+    info = c.learn_epoch(cols, 64, 2)
+    torch.cuda.synchronize()
+    outs.append((torch.stack([info[k] for k in sorted(info)]).clone(), c._flat.data.clone(), c.ac_net_optim.exp_avg_sq.clone()))
+  for x, y in zip(outs[0], outs[1]):
+    assert torch.equal(x, y)      # fixed summation order: bit for bit
+  # a shape outside the kernel's (two hidden layers wider than 64) runs the loop of learn() calls: same return type
+  wide = _make(3, 1, (128, 64), 1)
+  assert wide._fused is None
+  info = wide.learn_epoch(cols, 64, 1)
+  assert info['actor_loss'].shape == (5,) and wide.ac_net_optim.step_count == 5
+  # a TensorTupleDataset of the eight columns (examples/ppo.py:66) is taken as is
+  from torchrl_amd.utils.storage import TensorTupleDataset
+  d = lambda x: x.to(DEV)
+  ds = TensorTupleDataset(x=[d(obs), d(act), d(ret), d(obs), d(ret), d(ret), d(old), d(adv)])
+  c = _make(3, 1, (64, 64), 1)
+  info = c.learn_epoch(ds, 64, 2)
+  assert torch.equal(torch.stack([info[k] for k in sorted(info)]), outs[0][0])

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(LIB_DIR, 'libtrl_hip.so')
 # TRL_U8_FWD_WGS).  The production library above contains none of them and never reads the environment.
 TUNE_LIB_PATH = os.path.join(LIB_DIR, 'libtrl_hip_tune.so')
 SOURCES = ['trl_host.cpp', 'trl_replay.hip', 'trl_gae.hip', 'trl_loss.hip', 'trl_mlp.hip', 'trl_learn.hip',
-           'trl_offpolicy.hip', 'trl_linear_u8.hip', 'trl_act.hip']
+           'trl_offpolicy.hip', 'trl_linear_u8.hip', 'trl_act.hip', 'trl_epoch.hip']
 HEADERS = [os.path.join(CSRC, 'trl_common.h'), os.path.join(ROOT, 'include', 'trl_hip.h')]
 
 # -ffp-contract=off: the parity bar is the reference's op order, one f32 rounding per op.

@@ -28,11 +28,17 @@ class PPOController(Controller):
                                  device_state=graph)
     for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
       stack.direct_grads = True
+    self._epoch = None
     self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); TRL_FUSED_LEARN=0 disables
     if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
       lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
       if F.FusedPpoLearn.supports(lins[0], lins[1], self.ac_net.log_std):
         self._fused = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
+      # the minibatch loop in one launch (learn_epoch, csrc/trl_epoch.hip) takes some shapes the whole-step kernel does not
+      if self._fused is not None and self._fused.epoch_supported():
+        self._epoch = self._fused
+      elif F.FusedPpoLearn.epoch_supports(lins[0], lins[1], self.ac_net.log_std):
+        self._epoch = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma
@@ -154,3 +160,34 @@ class PPOController(Controller):
       self.ac_net_optim.step()
     self.ac_net_optim.note_step()
     return dict(actor_loss=parts[0], critic_loss=parts[1], entropy_loss=parts[2])
+
+  def learn_epoch(self, dataset, batch_size, n_epochs=1):
+    """The reference's learner loop -- `for epoch in range(n_epochs): for minibatch in DataLoader(dataset, batch_size):
+    self.learn(*minibatch)` (examples/ppo.py:66-73; sequential, un-shuffled, last partial batch kept) -- as ONE launch
+    where the networks allow it (functional.FusedPpoLearn.epoch_supported: a single rank, eager mode, one hidden layer
+    up to 256 wide or two up to 64, batch_size <= 4096): weights and Adam moments stay on the CU between the updates
+    (csrc/trl_epoch.hip).  Anything else runs the loop of learn() calls.
+
+    dataset: the eight columns of examples/ppo.py:66 -- a TensorTupleDataset, or a sequence (obs, action, reward,
+    next_obs, done, returns, old_log_probs, advantages); reward / next_obs / done are not read (may be None).
+    Returns dict(actor_loss, critic_loss, entropy_loss) of [K] tensors, one entry per learn() step in order."""
+    need_hip(self.device, 'PPOController.learn_epoch')
+    cols = dataset[:] if hasattr(dataset, 'truncate') else list(dataset)
+    if len(cols) != 8:
+      raise ValueError('learn_epoch takes the eight columns of examples/ppo.py:66, got %d' % len(cols))
+    obs, action, _reward, _next_obs, _done, returns, old_log_probs, advantages = cols
+    n, batch_size, n_epochs = obs.shape[0], int(batch_size), int(n_epochs)
+    f = self._epoch
+    if (f is not None and not self._sync.enabled and not self.ac_net_optim.device_state
+        and self._run.graphed is None and 1 <= batch_size <= f.EPOCH_MAX_MINIBATCH and obs.is_cuda and n >= 1):
+      losses = f.learn_epoch(obs, action, returns, old_log_probs, advantages, batch_size, n_epochs, self.clip_ratio,
+                             self.alpha, self.beta, self.ac_net_optim)
+      return dict(actor_loss=losses[:, 0], critic_loss=losses[:, 1], entropy_loss=losses[:, 2])
+    out = dict(actor_loss=[], critic_loss=[], entropy_loss=[])
+    for _ in range(n_epochs):
+      for s in range(0, n, batch_size):
+        e = min(n, s + batch_size)
+        info = self.learn(obs[s:e], action[s:e], None, None, None, returns[s:e], old_log_probs[s:e], advantages[s:e])
+        for k in out:
+          out[k].append(info[k].reshape(()))
+    return {k: torch.stack(v) for k, v in out.items()}

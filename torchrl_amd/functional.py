@@ -827,6 +827,69 @@ class FusedPpoLearn:
           self.log_std.grad.data_ptr(), aref, ws.data_ptr(), _lib.stream_ptr(dev)))
     return losses
 
+  # ---- the minibatch loop in one launch (trl_ppo_learn_epoch, csrc/trl_epoch.hip)
+  EPOCH_MAX_MINIBATCH = 4096
+
+  @staticmethod
+  def epoch_supports(critic_lin, actor_lin, log_std):
+    """Shapes the persistent minibatch-loop kernel takes (wider than the whole-step kernel's on some axes: up to four
+    actions at any width): one hidden layer (a multiple of 16, <= 256) or two (multiples of 16, <= 64) over at most 15
+    observations, PPO (a log_std), float32 parameters on a HIP device."""
+    if log_std is None or len(critic_lin) != len(actor_lin) or len(critic_lin) not in (2, 3):
+      return False
+    A = actor_lin[-1].out_features
+    if critic_lin[-1].out_features != 1 or not 1 <= A <= 4 or log_std.numel() != A:
+      return False
+    K0 = critic_lin[0].in_features
+    if K0 != actor_lin[0].in_features or K0 > 15:
+      return False
+    for lin in (critic_lin, actor_lin):
+      hid = [m.out_features for m in lin[:-1]]
+      if any(h % 16 or h < 16 for h in hid):
+        return False
+      if (len(hid) == 1 and hid[0] > 256) or (len(hid) == 2 and max(hid) > 64):
+        return False
+      for i, m in enumerate(lin):
+        if m.bias is None or m.weight.dtype != torch.float32 or not m.weight.is_cuda:
+          return False
+        if i > 0 and m.in_features != lin[i - 1].out_features:
+          return False
+    return True
+
+  def epoch_supported(self):
+    return FusedPpoLearn.epoch_supports(self.critic_lin, self.actor_lin, self.log_std)
+
+  def learn_epoch(self, obs, action, returns, old_logp, adv, minibatch, n_epochs, clip, alpha, beta, adam):
+    """K = n_epochs * ceil(n / minibatch) consecutive learn() steps over the consecutive row ranges of the columns
+    (examples/ppo.py:66-73), in one launch.  `adam` (optim.FlatAdam over the flat buffers of these parameters) has its
+    step count advanced by K.  Returns the [K, 4] loss tensor (actor, critic, entropy, total per step)."""
+    C = self._C
+    n = obs.shape[0]
+    obs = _f32c(obs, 'obs')
+    action = _f32c(action, 'action')
+    returns = _f32c(returns, 'returns')
+    old_logp = _f32c(old_logp, 'old_log_probs')
+    adv = _f32c(adv, 'advantages')
+    if obs.dim() != 2 or obs.shape[1] != self.K0 or action.numel() != n * self.A or old_logp.numel() != n * self.A \
+        or returns.numel() != n or adv.numel() != n:
+      raise ValueError('ppo_learn_epoch: inconsistent shapes')
+    if self._ptr_key() != self._key:
+      self._bind()
+    dev = obs.device
+    lib = _lib.lib()
+    minibatch, n_epochs = int(minibatch), int(n_epochs)
+    K = -(-n // minibatch) * n_epochs
+    ws = self._ws.get(dev, lib.trl_ppo_learn_epoch_workspace_bytes(n, minibatch, n_epochs))
+    losses = torch.empty((K, 4), dtype=torch.float32, device=dev)
+    a = adam.fused_args()                 # step = count of the first update
+    adam.step_count += K - 1
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_ppo_learn_epoch(
+          C.byref(self.descs[0]), C.byref(self.descs[1]), self.log_std.data_ptr(), obs.data_ptr(), action.data_ptr(),
+          returns.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), n, minibatch, n_epochs, self.A, float(clip),
+          float(alpha), float(beta), losses.data_ptr(), C.byref(a), ws.data_ptr(), _lib.stream_ptr(dev)))
+    return losses
+
   def a2c(self, obs, action, returns, alpha, beta, adam=None):
     """A2CController.learn's device work for A2CNet stacks (trl_a2c_learn_fused): a forward-only
     pass gives the detached advantage returns - V, then one launch for forward + loss + backward
