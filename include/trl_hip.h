@@ -407,6 +407,9 @@ int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor,
  *   (exact f32 products, torch's Adam op order) up to the order of the f32 sums.
  * `ws`: trl_ppo_learn_epoch_workspace_bytes() bytes of device scratch (the K steps' bias corrections). */
 int64_t trl_ppo_learn_epoch_workspace_bytes(int64_t n_rows, int64_t minibatch, int32_t n_epochs);
+/* 1 when trl_ppo_learn_epoch takes networks of these shapes (the limits above and the LDS the two workgroups need: a
+ * 256-wide hidden layer with four actions does not fit), 0 otherwise.  Only depth and dims of the descriptors are read. */
+int trl_ppo_learn_epoch_supported(const trl_mlp_desc *critic, const trl_mlp_desc *actor, int32_t A);
 int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std, const float *obs,
                         const float *action, const float *returns, const float *old_logp, const float *adv,
                         int64_t n_rows, int64_t minibatch, int32_t n_epochs, int32_t A, double clip, double alpha,

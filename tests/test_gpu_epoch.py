@@ -183,3 +183,19 @@ def test_learn_epoch_is_reproducible_and_falls_back():
   c = _make(3, 1, (64, 64), 1)
   info = c.learn_epoch(ds, 64, 2)
   assert torch.equal(torch.stack([info[k] for k in sorted(info)]), outs[0][0])
+
+
+def test_fast_adam_is_trl_adam_elem_bit_for_bit():
+  """The epoch kernel's Adam (divisions spelled out as reciprocal + two residual corrections, four elements at a time)
+  must be trl_adam_elem -- the library's one Adam, checked against torch.optim.Adam in tests/test_gpu_losses.py -- bit for
+  bit.  Runs tests/adam_compare_child.py on the diagnostic build (the comparison kernel lives there)."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  if not os.path.exists(os.path.join(root, 'torchrl_amd', 'lib', 'libtrl_hip_tune.so')):
+    pytest.skip('diagnostic build not present')
+  env = dict(os.environ, TRL_LIB='tune', PYTHONPATH=root)
+  r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'adam_compare_child.py')], env=env, capture_output=True,
+                     text=True, timeout=110)
+  assert r.returncode == 0 and 'adam compare child ok' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -38,7 +38,8 @@ class PPOController(Controller):
       if self._fused is not None and self._fused.epoch_supported():
         self._epoch = self._fused
       elif F.FusedPpoLearn.epoch_supports(lins[0], lins[1], self.ac_net.log_std):
-        self._epoch = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
+        cand = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
+        self._epoch = cand if cand.epoch_supported() else None
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma

@@ -10,22 +10,24 @@
 // one before it, so the loop cannot be spread over the chip; what it can do is never leave a CU.  And the critic and
 // the actor never meet: the loss is a sum of a critic term and actor terms, `advantages` and `returns` are inputs,
 // clip_grad_value_ and Adam are elementwise -- two independent chains.  So the launch is TWO workgroups, one per
-// network, each walking all minibatches of all epochs on its own CU:
+// network, each walking all minibatches of all epochs on its own CU (8 wavefronts, two per SIMD):
 //
-//   * the network's parameters and both Adam moments live in REGISTERS of the lane that owns them (the lane that holds
-//     the element of the weight-gradient product's accumulator tile), for the whole launch; LDS holds the copy of the
-//     weights the products read; the small vectors (last layer, its bias, hidden bias, log_std) live in LDS;
-//   * a minibatch is walked in tiles of 64 samples; all products are 16x16 output tiles of v_mfma_f32_16x16x4_f32
-//     (exact f32) with both operands read from LDS, k four at a time per lane: one ds_read_b128 where the reduction
-//     index is the contiguous one of the operand's LDS image, four ds_read_b32 (same bytes, same banks) where it is
-//     the strided one -- so every activation / gradient is stored ONCE, as [feature][sample];
-//   * the last layer (fan-out <= 4), the loss (k_ppo_loss's arithmetic, op for op), its backward seed and the masked
-//     outer product run on the VALU with lane = feature;
+//   * the hidden x hidden weight matrix and both its Adam moments live in REGISTERS of the lane that owns them -- the
+//     lane that holds that element of the weight-gradient product's accumulator tile -- for the whole launch; layer 0's
+//     and the small vectors' (last layer, biases, log_std) state is spread one element per thread; LDS holds the
+//     copies of the weights the products read;
+//   * a minibatch is walked in tiles of 64 samples; every product is a 16x16 output tile of v_mfma_f32_16x16x4_f32
+//     (exact f32) with both operands read from LDS with the reduction index contiguous (one ds_read_b128 feeds four
+//     MFMAs), which is why activations / gradients / W1 that are summed over along either index are kept in both
+//     orientations (the second copy is 4 extra 4 B stores per tile element);
+//   * the last layer (fan-out <= 4) is folded into the epilogue of the tile that produces its input: a 16-lane DPP
+//     row sum per output; the loss (k_ppo_loss's arithmetic, op for op) runs on one wave, lane = sample; the masked
+//     outer product and the last layer's gradient run with lane = feature;
 //   * clip_grad_value_ + Adam (trl_adam_elem: torch's op order) are applied by the owning lane straight from the
 //     accumulator; the step's bias corrections come from a table a small launch derives ahead (double precision).
 //
 // Results: the same arithmetic as trl_ppo_learn_fused up to the order of the f32 sums (tests/test_gpu_epoch.py: K
-// consecutive learn() calls and the oracle's torch-CPU loop).
+// consecutive learn() calls, the oracle's torch-CPU loop, the reference's golden two-step fixture).
 #include <string.h>
 
 #include "trl_common.h"
@@ -34,9 +36,11 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 512, NW = 8;     // threads, wavefronts per workgroup (two per SIMD)
+constexpr int NW = 8, NT = 64 * NW;  // wavefronts (two per SIMD: 256 registers each), threads per workgroup
+constexpr int T1 = 16 / NW;         // accumulator tiles a wave owns of a product with up to 16 output tiles
+constexpr int U0 = 4096 / NT;       // layer-0 elements a thread owns at most (256 x 16)
 constexpr int S = 64;               // samples per tile
-constexpr int LDS_S = S + 4;        // row stride of a [feature][sample] image: 16 lanes x 16 B on 16 distinct bank quads
+constexpr int LS = S + 4;           // row stride (floats) of every 64-column LDS image: 16 lanes x 16 B on 16 distinct bank quads
 constexpr int KP = 16;              // fan-in + 1 (the bias column), padded to one k round
 constexpr int LDK = KP + 4;
 constexpr int MAXO = 4;
@@ -58,78 +62,121 @@ struct Args {
   int B, n_epochs, A;
   float lo, hi, alpha, beta, clip;
   float w1, beta2, c2, eps;  // Adam's step-independent scalars
-  const float *steps;        // [K][2]: bc2_sqrt, neg_step of update k (k_epoch_prep)
+  const float *steps;        // [K][4]: bc2_sqrt, neg_step, RN(1 / bc2_sqrt), - of update k (k_epoch_prep)
   float *losses;             // [K][4]
 };
 
-// LDS map of one workgroup (offsets in floats)
+// LDS map of one workgroup (offsets in floats).  Aliases: g2 (the [sample][feature] copy of layer 1's output gradient)
+// lives where h1's [sample][feature] copy was (dead once layer 1 has run); at update time -- every product of the
+// minibatch done -- the partial sums of the lane = feature pass lie over h1 / h1t and layer 0's flushed gradient over h2t.
 struct Lay {
-  int xpt[2], w0p, h1t, h2t, w1, red, gout, part, vp_p, vp_m, vp_v, vp_g, total;
-  int ldw1, HL, HLP, wpb, NV, o_wl, o_bl, o_b1, o_ls;
+  int xp[2], xpt[2], w0p, gw0, h1, h1t, h2t, g1t, w1, w1t, red, gout, part, vp_p, vp_m, vp_v, tail_g, total;
+  int HL, HLP, NB, wpb, nred, NV, o_bl, o_b1, o_ls, PO;
 };
 
 __host__ __device__ inline Lay make_lay(const Net &n) {
   Lay L;
   int o = 0;
   auto take = [&](int f) { int at = o; o += (f + 3) / 4 * 4; return at; };
-  L.xpt[0] = take(KP * LDS_S);
-  L.xpt[1] = take(KP * LDS_S);
+  const bool d3 = n.depth == 3;
+  L.HL = d3 ? n.H2 : n.H1;
+  L.NB = (L.HL + 63) / 64;
+  L.HLP = L.NB * 64;
+  L.wpb = L.NB == 1 ? NW : (L.NB == 2 ? NW / 2 : NW / 4);      // wavefronts per block of 64 features in the lane = feature pass
+  // partial dot products of the last layer, one plane per slot: two hidden layers -> a slot per 16 features of h2; one
+  // hidden layer -> a wave sums over its own tiles first, slot = w >> 2
+  L.nred = d3 ? L.HL / 16 : (L.HL / 16 < NW / 4 ? L.HL / 16 : NW / 4);
+  L.PO = n.O + (d3 ? 1 : 0);                         // partial-sum planes: dwL[o] and (two hidden layers) db1
+  L.xp[0] = take(S * LDK);
+  L.xp[1] = take(S * LDK);
+  L.xpt[0] = take(KP * LS);
+  L.xpt[1] = take(KP * LS);
   L.w0p = take(n.H1 * LDK);
-  L.h1t = take(n.H1 * LDS_S);
-  L.ldw1 = n.H1 + 4;
-  L.h2t = n.depth == 3 ? take(n.H2 * LDS_S) : 0;
-  L.w1 = n.depth == 3 ? take(n.H2 * L.ldw1) : 0;
-  L.HL = n.depth == 3 ? n.H2 : n.H1;
-  const int NB = (L.HL + 63) / 64;
-  L.HLP = NB * 64;
-  L.wpb = NW / NB;           // wavefronts per block of 64 features in the lane = feature pass
-  L.red = take(NW * MAXO * S);
-  L.gout = take(MAXO * LDS_S);
-  L.part = take(L.wpb * (MAXO + 1) * L.HLP);
-  L.o_wl = 0;
+  const int part_f = L.wpb * L.PO * L.HLP;
+  if (d3) {
+    L.h1 = take(S * LS);
+    L.h1t = take(n.H1 * LS);
+    if (part_f > o - L.h1) o = L.h1 + (part_f + 3) / 4 * 4;
+    L.part = L.h1;
+    L.h2t = take(n.H2 * LS > n.H1 * LDK ? n.H2 * LS : n.H1 * LDK);
+    L.gw0 = L.h2t;
+    L.g1t = take(n.H1 * LS);
+    L.w1 = take(n.H2 * LS);
+    L.w1t = take(n.H1 * LS);
+  } else {
+    L.h1 = 0;
+    L.h1t = take(n.H1 * LS);
+    L.h2t = L.h1t;
+    L.g1t = L.h1t;
+    L.w1 = L.w1t = 0;
+    L.part = take(part_f);
+    L.gw0 = take(n.H1 * LDK);
+  }
+  L.red = take(L.nred * n.O * LS);
+  L.gout = take(n.O * LS);
   L.o_bl = n.O * L.HL;
   L.o_b1 = L.o_bl + n.O;
-  L.o_ls = L.o_b1 + (n.depth == 3 ? n.H2 : 0);
+  L.o_ls = L.o_b1 + (d3 ? n.H2 : 0);
   L.NV = L.o_ls + (n.ls_off >= 0 ? n.O : 0);
   L.vp_p = take(L.NV);
   L.vp_m = take(L.NV);
   L.vp_v = take(L.NV);
-  L.vp_g = take(L.NV);
+  L.tail_g = take(L.NV - L.o_bl);
   L.total = o;
   return L;
 }
 
-// Two 16x16 output tiles at once (independent accumulators: the f32 MFMA's dependent latency is 40 cycles against 32
-// of issue).  Operand X of tile t: element (row-or-column i, reduction index k) at X[i * ld + k] when XKC (k contiguous:
-// one 16 B read per four k) or X[k * ld + i] (k strided: four 4 B reads).  Lane (i = lane & 15, q = lane >> 4) supplies
-// k = k0 + 4 q + c to the c-th MFMA of a round for both operands, so any k order is the same sum.
-template <bool AKC, bool BKC>
-__device__ __forceinline__ void mma2(const float *A0, const float *A1, int lda, const float *B0, const float *B1, int ldb,
-                                     int K, v4f &acc0, v4f &acc1, int i, int q) {
-  auto ld = [&](const float *X, int ldx, bool kc, int k0, float (&r)[4]) {
-    if (kc) {
-      const v4f t = *(const v4f *)(X + i * ldx + k0 + 4 * q);
-      r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-    } else {
-      const float *p = X + (k0 + 4 * q) * ldx + i;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) r[c] = p[c * ldx];
-    }
-  };
-  float a0[4], a1[4], b0[4], b1[4];
-  ld(A0, lda, AKC, 0, a0); ld(A1, lda, AKC, 0, a1); ld(B0, ldb, BKC, 0, b0); ld(B1, ldb, BKC, 0, b1);
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    float na0[4], na1[4], nb0[4], nb1[4];
-    const int kn = k0 + 16 < K ? k0 + 16 : k0;      // (the last round re-reads itself: no branch around the loads)
-    ld(A0, lda, AKC, kn, na0); ld(A1, lda, AKC, kn, na1); ld(B0, ldb, BKC, kn, nb0); ld(B1, ldb, BKC, kn, nb1);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b0[c], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b1[c], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { a0[c] = na0[c]; a1[c] = na1[c]; b0[c] = nb0[c]; b1[c] = nb1[c]; }
+// One 16x16 output tile: sum over k of A[row i][k] * B[col i][k], both operands k-contiguous in LDS (row strides LDA,
+// LDB floats), K a multiple of 16.  Lane (i = lane & 15, q = lane >> 4) supplies k = k0 + 4 q + c to the c-th MFMA of a
+// round for both operands, so any k order is the same sum; the next round's 16 B reads are issued ahead of the MFMAs.
+template <int LDA, int LDB>
+__device__ __forceinline__ v4f mma(const float *A, const float *B, int K, v4f acc, int i, int q) {
+  const float *pa = A + i * LDA + 4 * q, *pb = B + i * LDB + 4 * q;
+  v4f a = *(const v4f *)pa, b = *(const v4f *)pb;
+  for (int k0 = 16; k0 < K; k0 += 16) {
+    const v4f na = *(const v4f *)(pa + k0), nb = *(const v4f *)(pb + k0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    a = na;
+    b = nb;
   }
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  return acc;
+}
+
+// Two tiles in one loop (independent accumulators: a wave's own MFMAs then fill the dependent-issue gap, 40 cycles
+// against 32); the tiles usually share one operand (same pointer passed twice).
+template <int LDA, int LDB>
+__device__ __forceinline__ void mma2(const float *A0, const float *A1, const float *B0, const float *B1, int K, v4f &acc0,
+                                     v4f &acc1, int i, int q) {
+  const int oa = i * LDA + 4 * q, ob = i * LDB + 4 * q;
+  v4f a0 = *(const v4f *)(A0 + oa), a1 = *(const v4f *)(A1 + oa), b0 = *(const v4f *)(B0 + ob), b1 = *(const v4f *)(B1 + ob);
+  for (int k0 = 16; k0 < K; k0 += 16) {
+    const v4f na0 = *(const v4f *)(A0 + oa + k0), na1 = *(const v4f *)(A1 + oa + k0), nb0 = *(const v4f *)(B0 + ob + k0),
+              nb1 = *(const v4f *)(B1 + ob + k0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+  }
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
 }
 
 __device__ __forceinline__ v4f relu4(v4f x) {
@@ -137,22 +184,79 @@ __device__ __forceinline__ v4f relu4(v4f x) {
   return x;
 }
 
-// a parameter tile owned by this lane for the whole launch: accumulator element r is (row m0 + 4 q + r, column c0 + i)
-struct Owned {
-  v4f p, m, v, acc;
+__device__ __forceinline__ v4f mask4(v4f g, v4f h) {
+  g.x = h.x > 0.f ? g.x : 0.f; g.y = h.y > 0.f ? g.y : 0.f; g.z = h.z > 0.f ? g.z : 0.f; g.w = h.w > 0.f ? g.w : 0.f;
+  return g;
+}
+
+// sum over the 16 lanes of a DPP row (the lanes that share q), the same bits in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float x) {
+  x += dpp_f<0xB1>(x);       // quad_perm [1, 0, 3, 2]
+  x += dpp_f<0x4E>(x);       // quad_perm [2, 3, 0, 1]
+  x += dpp_f<0x141>(x);      // row_half_mirror
+  x += dpp_f<0x140>(x);      // row_mirror
+  return x;
+}
+
+// ---- clip_grad_value_ + Adam on four elements at once, trl_adam_elem's arithmetic (torch's op order, one f32 rounding
+// per op) with the two IEEE divisions spelled out so that they cost what they must and no more:
+//   * sqrt(v) / bias_correction2_sqrt divides by a per-step CONSTANT c: with rc = RN(1 / c) from the step table the
+//     quotient is q0 = x rc, two residual corrections r = fma(-c, q, x), q += r rc -- the refinement the compiler's
+//     own expansion ends with, minus its range scaling (x = sqrt(v) >= 0 and c in (0.03, 1]: nothing to scale; a
+//     subnormal x may come out an ulp of a subnormal off, and is then added to eps);
+//   * (step_size m) / denom: v_rcp_f32 seed, one Newton step, the same two residual corrections; denom >= eps, the
+//     quotient is far from overflow, and a quotient in the subnormal range is added to a parameter.
+// Correctly rounded quotients are unique, so in the ranges above these are the bits of __fdiv_rn
+// (tests/test_gpu_epoch.py::test_fast_adam_is_trl_adam_elem_bit_for_bit, on the diagnostic build).  Written on 4-vectors:
+// the multiplies, adds and fmas pair up as v_pk_*_f32.  clip = +inf means none (med3 then returns the gradient).
+struct AdamV {
+  float w1, beta2, c2, eps, clip, c, rc, neg_step;
 };
 
-__device__ __forceinline__ void adam4(Owned &t, const TrlAdamScalars &s, v4f &g_out) {
-  float p[4] = {t.p.x, t.p.y, t.p.z, t.p.w}, m[4] = {t.m.x, t.m.y, t.m.z, t.m.w}, v[4] = {t.v.x, t.v.y, t.v.z, t.v.w},
-        g[4] = {t.acc.x, t.acc.y, t.acc.z, t.acc.w};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) trl_adam_elem(&p[r], &g[r], &m[r], &v[r], s);
-  t.p = (v4f){p[0], p[1], p[2], p[3]};
-  t.m = (v4f){m[0], m[1], m[2], m[3]};
-  t.v = (v4f){v[0], v[1], v[2], v[3]};
-  g_out = (v4f){g[0], g[1], g[2], g[3]};
-  t.acc = (v4f){0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v4f splat(float x) { return (v4f){x, x, x, x}; }
+
+__device__ __forceinline__ void adam4(v4f &p, v4f &g, v4f &m, v4f &v, const AdamV s) {
+  g.x = __builtin_amdgcn_fmed3f(g.x, -s.clip, s.clip); g.y = __builtin_amdgcn_fmed3f(g.y, -s.clip, s.clip);
+  g.z = __builtin_amdgcn_fmed3f(g.z, -s.clip, s.clip); g.w = __builtin_amdgcn_fmed3f(g.w, -s.clip, s.clip);
+  m = m + splat(s.w1) * (g - m);                                  // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * splat(s.beta2) + (splat(s.c2) * g) * g;                 // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+  const v4f x = {__fsqrt_rn(v.x), __fsqrt_rn(v.y), __fsqrt_rn(v.z), __fsqrt_rn(v.w)};
+  const v4f c = splat(s.c), rc = splat(s.rc);
+  v4f q = x * rc;
+  q = vfma(vfma(-c, q, x), rc, q);
+  q = vfma(vfma(-c, q, x), rc, q);
+  const v4f den = q + splat(s.eps);                               // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+  const v4f n = splat(s.neg_step) * m;
+  v4f y = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z), __builtin_amdgcn_rcpf(den.w)};
+  y = vfma(vfma(-den, y, splat(1.0f)), y, y);
+  v4f d = n * y;
+  d = vfma(vfma(-den, d, n), y, d);
+  d = vfma(vfma(-den, d, n), y, d);
+  p = p + d;                                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
+
+__device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, const AdamV s) {
+  v4f pp = splat(p), gg = splat(g), mm = splat(m), vv = splat(v);
+  adam4(pp, gg, mm, vv, s);
+  p = pp.x; g = gg.x; m = mm.x; v = vv.x;
+}
+
+#ifdef TRL_TUNING      // diagnostic build: clock stamps of wave 0 at the phase boundaries of one update (tools/epoch_stamps.py)
+__device__ unsigned long long g_epoch_stamp[2][16];
+#define STAMP(j)                                                                                 \
+  do {                                                                                           \
+    if (tid == 0 && k == K / 2 && t == 0) g_epoch_stamp[role][j] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define STAMP(j) \
+  do {           \
+  } while (0)
+#endif
 
 // the update table: bias corrections of steps step0 .. step0 + K - 1 (torch: bias_correction2 ** 0.5 and lr / bias_correction1,
 // in double, narrowed at the point of use)
@@ -160,8 +264,10 @@ __global__ void k_epoch_prep(float *steps, int K, double lr, double beta1, doubl
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < K) {
     const TrlAdamScalars s = trl_adam_scalars(lr, beta1, beta2, eps, step0 + k, 1.0, 0.0);
-    steps[2 * k] = s.bc2_sqrt;
-    steps[2 * k + 1] = s.neg_step;
+    steps[4 * k] = s.bc2_sqrt;
+    steps[4 * k + 1] = s.neg_step;
+    steps[4 * k + 2] = (float)(1.0 / (double)s.bc2_sqrt);      // RN(1 / c) of the f32 constant c the division uses
+    steps[4 * k + 3] = 0.f;
   }
 }
 
@@ -170,63 +276,82 @@ __global__ void k_epoch_totals(float *losses, int K, float alpha, float beta) {
   if (k < K) losses[4 * k + 3] = (losses[4 * k] + alpha * losses[4 * k + 1]) - beta * losses[4 * k + 2];
 }
 
-template <int role>      // 0 critic, 1 actor
+// role: 0 critic, 1 actor; D3: two hidden layers; O: the network's fan-out
+template <int role, bool D3, int O>
 __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   const Net &N = P.net[role];
   const Lay L = make_lay(N);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, q = lane >> 4;
-  const bool d3 = N.depth == 3;
-  const int H1 = N.H1, H2 = N.H2, O = N.O, HL = L.HL, d0 = N.d0, A = P.A;
-  float *xpt[2] = {lds + L.xpt[0], lds + L.xpt[1]};
-  float *w0p = lds + L.w0p, *h1t = lds + L.h1t, *h2t = lds + L.h2t, *w1 = lds + L.w1, *red = lds + L.red,
-        *gout = lds + L.gout, *part = lds + L.part, *vpp = lds + L.vp_p, *vpm = lds + L.vp_m, *vpv = lds + L.vp_v,
-        *vpg = lds + L.vp_g;
-  float *hlt = d3 ? h2t : h1t;               // the last hidden layer's image
-  const int ldw1 = L.ldw1;
+  const int H1 = N.H1, H2 = N.H2, HL = L.HL, d0 = N.d0;
+  float *w0p = lds + L.w0p, *gw0 = lds + L.gw0, *h1 = lds + L.h1, *h1t = lds + L.h1t, *h2t = lds + L.h2t, *g1t = lds + L.g1t,
+        *w1 = lds + L.w1, *w1t = lds + L.w1t, *red = lds + L.red, *gout = lds + L.gout, *part = lds + L.part,
+        *vpp = lds + L.vp_p, *vpm = lds + L.vp_m, *vpv = lds + L.vp_v, *tailg = lds + L.tail_g;
+  const int xp0 = L.xp[0], xp1 = L.xp[1], xpt0 = L.xpt[0], xpt1 = L.xpt[1];      // (no run-time index into the map: that would put it on the stack)
+  float *hlt = D3 ? h2t : h1t;               // the last hidden layer's [feature][sample] image
+  float *g2 = h1;                            // (alias, see Lay)
 
-  // ---- ownership of the two weight matrices.  Main product (depth 3: dW1 [H2][H1]; depth 2: dW0' [H1][KP]): tiles
-  // w and w + NW; depth 3 also owns dW0' tile w (w < H1 / 16) in the third slot.
-  const int KT1 = d3 ? H1 / 16 : 1;                        // column tiles of the main product
-  const int nmain = d3 ? (H2 / 16) * KT1 : H1 / 16;
-  Owned own[3];
-  int t_row[3], t_col[3];
-  bool t_ok[3], t_is_w1[3];
+  // ---- ownership.  W1 (two hidden layers): tiles w + NW u of dW1 [H2][H1], element r of an accumulator = (row r1 + 4 q + r,
+  // column c1 + i): both moments in this lane's registers, the parameter itself in LDS (w1 / w1t).  Layer 0's
+  // [W0 | b0]: element e = tid + u * NT, moments in registers, parameter in LDS (w0p).
+  const int KT1 = D3 ? H1 / 16 : 1;
+  bool own1[T1];
+  int r1[T1], c1[T1];
+  v4f m1[T1], v1[T1], acc1[T1];
 #pragma unroll
-  for (int sl = 0; sl < 3; ++sl) {
-    const int t = sl < 2 ? w + NW * sl : w;
-    t_is_w1[sl] = d3 && sl < 2;
-    t_ok[sl] = sl < 2 ? t < nmain : (d3 && t < H1 / 16);
-    t_row[sl] = (t_is_w1[sl] ? t / KT1 : t) * 16;
-    t_col[sl] = (t_is_w1[sl] ? t % KT1 : 0) * 16;
-    own[sl].acc = (v4f){0.f, 0.f, 0.f, 0.f};
-    float p[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
-    if (t_ok[sl]) {
+  for (int u = 0; u < T1; ++u) {
+    const int tt = w + NW * u;
+    own1[u] = D3 && tt < (H2 / 16) * KT1;
+    r1[u] = (tt / KT1) * 16;
+    c1[u] = (tt % KT1) * 16;
+    m1[u] = v1[u] = acc1[u] = (v4f){0, 0, 0, 0};
+    if (own1[u]) {
+      float p[4], m[4], v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = t_row[sl] + 4 * q + r, col = t_col[sl] + i;
-        int64_t g = -1;
-        if (t_is_w1[sl]) g = N.w_off[1] + (int64_t)row * H1 + col;
-        else if (col < d0) g = N.w_off[0] + (int64_t)row * d0 + col;
-        else if (col == d0) g = N.b_off[0] + row;
-        if (g >= 0) { p[r] = P.param[g]; m[r] = P.m[g]; v[r] = P.v[g]; }
-        if (t_is_w1[sl]) w1[row * ldw1 + col] = p[r];
-        else w0p[row * LDK + col] = p[r];
+        const int64_t g = N.w_off[1] + (int64_t)(r1[u] + 4 * q + r) * H1 + c1[u] + i;
+        p[r] = P.param[g]; m[r] = P.m[g]; v[r] = P.v[g];
+        w1[(r1[u] + 4 * q + r) * LS + c1[u] + i] = p[r];
+      }
+      m1[u] = (v4f){m[0], m[1], m[2], m[3]}; v1[u] = (v4f){v[0], v[1], v[2], v[3]};
+      *(v4f *)(w1t + (c1[u] + i) * LS + r1[u] + 4 * q) = (v4f){p[0], p[1], p[2], p[3]};
+    }
+  }
+  // layer 0: the padded [H1][KP] image, element e = (row n = e >> 4, column j = e & 15); j < d0 a weight, j == d0 the
+  // bias, j > d0 padding (zero parameter, zero gradient: the update leaves it zero; it is never written back)
+  const int n0e = H1 * KP;
+  auto w0_global = [&](int e) -> int64_t {
+    const int n = e >> 4, j = e & 15;
+    return j < d0 ? N.w_off[0] + (int64_t)n * d0 + j : (j == d0 ? N.b_off[0] + n : -1);
+  };
+  float m0[U0], v0[U0];
+  for (int e = tid; e < H1 * LDK; e += NT) w0p[e] = 0.f;      // (the padding columns stay zero for good)
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U0; ++u) {
+    const int e = tid + u * NT;
+    m0[u] = v0[u] = 0.f;
+    if (e < n0e) {
+      const int64_t g = w0_global(e);
+      if (g >= 0) {
+        m0[u] = P.m[g]; v0[u] = P.v[g];
+        w0p[(e >> 4) * LDK + (e & 15)] = P.param[g];
       }
     }
-    own[sl].p = (v4f){p[0], p[1], p[2], p[3]};
-    own[sl].m = (v4f){m[0], m[1], m[2], m[3]};
-    own[sl].v = (v4f){v[0], v[1], v[2], v[3]};
   }
-  // the small vectors: last layer [O][HL], its bias [O], hidden bias b1 [H2] (depth 3), log_std [A] (actor)
+  bool own0[T1];      // accumulator tiles w + NW u of dW0' [H1][KP]
+  v4f acc0[T1];
+#pragma unroll
+  for (int u = 0; u < T1; ++u) { own0[u] = w + NW * u < H1 / 16; acc0[u] = (v4f){0, 0, 0, 0}; }
+  // the small vectors: last layer [O][HL], its bias [O], hidden bias b1 [H2] (two hidden layers), log_std [O] (actor)
   auto vp_global = [&](int e) -> int64_t {
-    if (e < L.o_bl) return N.w_off[N.depth - 1] + e;
-    if (e < L.o_b1) return N.b_off[N.depth - 1] + (e - L.o_bl);
+    if (e < L.o_bl) return N.w_off[D3 ? 2 : 1] + e;
+    if (e < L.o_b1) return N.b_off[D3 ? 2 : 1] + (e - L.o_bl);
     if (e < L.o_ls) return N.b_off[1] + (e - L.o_b1);
     return N.ls_off + (e - L.o_ls);
   };
   for (int e = tid; e < L.NV; e += NT) {
     const int64_t g = vp_global(e);
-    vpp[e] = P.param[g]; vpm[e] = P.m[g]; vpv[e] = P.v[g]; vpg[e] = 0.f;
+    vpp[e] = P.param[g]; vpm[e] = P.m[g]; vpv[e] = P.v[g];
   }
 
   const int B = P.B;
@@ -234,13 +359,18 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   const int mb_per_epoch = (int)((n_rows + B - 1) / B);
   const int K = mb_per_epoch * P.n_epochs;
 
-  // ---- input prefetch: a tile's observations are 64 * d0 consecutive floats (consecutive rows); thread t takes
-  // elements t and t + NT.  Wave 0's lane s also carries sample s's loss inputs.
-  float xin[2] = {0.f, 0.f};
-  float in_act[MAXO] = {0, 0, 0, 0}, in_old[MAXO] = {0, 0, 0, 0}, in_adv = 0.f, in_ret = 0.f;
+  // ---- input prefetch: a tile's observations are 64 * d0 consecutive floats (consecutive rows), one per thread.
+  // Wave 0's lane s also carries sample s's loss inputs.
+  constexpr int XU = (S * (KP - 1) + NT - 1) / NT;
+  float xin[XU];
+#pragma unroll
+  for (int u = 0; u < XU; ++u) xin[u] = 0.f;
+  float in_act[O], in_old[O], in_adv = 0.f, in_ret = 0.f;
+#pragma unroll
+  for (int a = 0; a < O; ++a) in_act[a] = in_old[a] = 0.f;
   auto prefetch = [&](int64_t row0, int rows) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < XU; ++u) {
       const int e = tid + u * NT;
       xin[u] = e < rows * d0 ? P.obs[row0 * d0 + e] : 0.f;
     }
@@ -252,22 +382,27 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       } else {
         in_adv = ok ? P.adv[r] : 0.f;
 #pragma unroll
-        for (int a = 0; a < MAXO; ++a)
-          if (a < A) { in_act[a] = ok ? P.action[r * A + a] : 0.f; in_old[a] = ok ? P.old_logp[r * A + a] : 0.f; }
+        for (int a = 0; a < O; ++a) { in_act[a] = ok ? P.action[r * O + a] : 0.f; in_old[a] = ok ? P.old_logp[r * O + a] : 0.f; }
       }
     }
   };
-  // registers -> the x' image [KP][S]: rows j < d0 the observation, row d0 ones (the bias column), the rest and every
-  // column of a sample beyond the minibatch zeros (such a sample then contributes exact zeros everywhere downstream)
-  auto store_x = [&](float *X, int rows) {
+  // registers -> the x' images [S][KP] and [KP][S]: columns j < d0 the observation, column d0 ones (the bias), the rest
+  // -- and every entry of a sample beyond the minibatch -- zeros (such a sample contributes exact zeros downstream)
+  auto store_x = [&](float *X, float *XT, int rows) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < XU; ++u) {
       const int e = tid + u * NT;
-      if (e < S * d0) { const int s = e / d0, j = e - s * d0; X[j * LDS_S + s] = xin[u]; }
+      if (e < S * d0) {
+        const int s = e / d0, j = e - s * d0;
+        X[s * LDK + j] = xin[u];
+        XT[j * LS + s] = xin[u];
+      }
     }
     for (int e = tid; e < (KP - d0) * S; e += NT) {
-      const int j = d0 + e / S, s = e % S;
-      X[j * LDS_S + s] = (j == d0 && s < rows) ? 1.f : 0.f;
+      const int s = e & 63, j = d0 + (e >> 6);
+      const float v = (j == d0 && s < rows) ? 1.f : 0.f;
+      X[s * LDK + j] = v;
+      XT[j * LS + s] = v;
     }
   };
   auto tile_of = [&](int k, int t, int64_t &row0, int &rows, int &bm) {      // update k, tile t -> rows of the data
@@ -278,98 +413,153 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     rows = bm - t * S < S ? bm - t * S : S;
   };
 
+  // Input pipeline, two tiles deep: at the top of tile T the registers hold tile T + 1 (loaded during tile T - 1: long
+  // arrived), they go to the other x' buffers, and the loads of tile T + 2 are issued into them -- a load is never
+  // waited for less than a whole tile after its issue (an observation row comes from HBM the first time: ~2 us).
+  auto advance = [&](int &k, int &t) {      // the tile after (k, t); k == K when there is none
+    int64_t r0; int rr, bm;
+    tile_of(k, 0, r0, rr, bm);
+    if ((t + 1) * S < bm) { ++t; } else { ++k; t = 0; }
+  };
   int cur = 0;
+  int pk = 0, pt = 0;              // the tile the registers hold / are loading
+  int prow = 0;                    // its row count
   {
-    int64_t row0; int rows, bm;
-    tile_of(0, 0, row0, rows, bm);
-    prefetch(row0, rows);
-    store_x(xpt[0], rows);
+    int64_t row0; int bm;
+    tile_of(0, 0, row0, prow, bm);
+    prefetch(row0, prow);
+    store_x(lds + L.xp[0], lds + L.xpt[0], prow);
   }
-  float cur_act[MAXO], cur_old[MAXO], cur_adv = in_adv, cur_ret = in_ret;
+  float cur_act[O], cur_old[O], cur_adv = in_adv, cur_ret = in_ret;
+  float nxt_act[O], nxt_old[O], nxt_adv = 0.f, nxt_ret = 0.f;
 #pragma unroll
-  for (int a = 0; a < MAXO; ++a) { cur_act[a] = in_act[a]; cur_old[a] = in_old[a]; }
+  for (int a = 0; a < O; ++a) { cur_act[a] = in_act[a]; cur_old[a] = in_old[a]; nxt_act[a] = nxt_old[a] = 0.f; }
+  advance(pk, pt);
+  if (pk < K) {
+    int64_t row0; int bm;
+    tile_of(pk, pt, row0, prow, bm);
+    prefetch(row0, prow);
+  }
   __syncthreads();
 
   // lane = feature pass: this wave's block of 64 features and its share of the tile's samples
   const int gp_nb = w / L.wpb, gp_sr = w % L.wpb, gp_ns = S / L.wpb;
   const int gp_n = gp_nb * 64 + lane;
-  const bool gp_on = gp_nb * 64 < HL && gp_n < HL;
+  const bool gp_on = gp_nb < L.NB && gp_n < HL;
+  // forward tiles of the last hidden layer: this wave's sample tile and slot of partial dot products
+  const int f_s0 = (w & 3) * 16;
 
   for (int k = 0; k < K; ++k) {
     int bm;
     { int64_t r0; int rr; tile_of(k, 0, r0, rr, bm); }
     const int ntile = (bm + S - 1) / S;
     const float invB = 1.0f / (float)bm;
-    const float bc2_sqrt = P.steps[2 * k], neg_step = P.steps[2 * k + 1];
-    float a_crit = 0.f, a_min = 0.f, a_ent = 0.f, a_dls[MAXO] = {0, 0, 0, 0}, a_gb[MAXO] = {0, 0, 0, 0};
-    float dwl[MAXO] = {0, 0, 0, 0}, db1 = 0.f;
+    const v4f step_k = *(const v4f *)(P.steps + 4 * k);
+    float a_crit = 0.f, a_min = 0.f, a_ent = 0.f, a_dls[O], a_gb[O], dwl[O], db1 = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) a_dls[o] = a_gb[o] = dwl[o] = 0.f;
 
     for (int t = 0; t < ntile; ++t) {
-      const float *X = xpt[cur];
+      const float *X = lds + (cur ? xp1 : xp0), *XT = lds + (cur ? xpt1 : xpt0);
       int rows_t;
       { int64_t r0; int b2; tile_of(k, t, r0, rows_t, b2); }
-      // the tile after this one (next tile of the minibatch, or the first of the next update): loads in flight from here
-      const bool more = t + 1 < ntile || k + 1 < K;
-      int64_t nrow0 = 0; int nrows = 0;
-      if (more) { int b2; tile_of(t + 1 < ntile ? k : k + 1, t + 1 < ntile ? t + 1 : 0, nrow0, nrows, b2); prefetch(nrow0, nrows); }
+      // registers (tile T + 1) -> the other x' buffers and wave 0's "next" loss inputs; then the loads of tile T + 2
+      const bool more = pk < K;
+      if (more) {
+        store_x(lds + (cur ? xp0 : xp1), lds + (cur ? xpt0 : xpt1), prow);
+        nxt_adv = in_adv; nxt_ret = in_ret;
+#pragma unroll
+        for (int a = 0; a < O; ++a) { nxt_act[a] = in_act[a]; nxt_old[a] = in_old[a]; }
+        advance(pk, pt);
+        if (pk < K) {
+          int64_t row0; int bm;
+          tile_of(pk, pt, row0, prow, bm);
+          prefetch(row0, prow);
+        }
+      }
 
-      // ---- layer 0: h1[s][n] = relu(x'[s] . W0'[n]) as C[s][n] tiles -> [feature][sample] image, 16 B stores
+      STAMP(0);
+      // ---- layer 0: h1[s][n] = relu(x'[s] . W0'[n]) as C[s][n] tiles (lane: 4 consecutive samples of feature n0 + i).
+      // One hidden layer: the last layer's dot products ride in the epilogue (16-lane row sums), partials per slot.
       {
         const int ntl = 4 * (H1 / 16);
-        for (int t0 = w; t0 < ntl; t0 += 2 * NW) {
-          const bool two = t0 + NW < ntl;
-          const int t1 = two ? t0 + NW : t0;
-          const int s0 = (t0 & 3) * 16, n0 = (t0 >> 2) * 16, n1 = (t1 >> 2) * 16;      // (t1 & 3 == t0 & 3)
-          v4f c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-          mma2<false, true>(X + s0, X + s0, LDS_S, w0p + n0 * LDK, w0p + n1 * LDK, LDK, KP, c0, c1, i, q);
-          *(v4f *)(h1t + (n0 + i) * LDS_S + s0 + 4 * q) = relu4(c0);
-          if (two) *(v4f *)(h1t + (n1 + i) * LDS_S + s0 + 4 * q) = relu4(c1);
+        float pr[O][4];
+#pragma unroll
+        for (int o = 0; o < O; ++o) pr[o][0] = pr[o][1] = pr[o][2] = pr[o][3] = 0.f;
+        for (int t0 = w; t0 < ntl; t0 += NW) {
+          const int n0 = (t0 >> 2) * 16;      // (t0 & 3 == w & 3: the wave's sample tile)
+          float wl[O];
+#pragma unroll
+          for (int o = 0; o < O; ++o) wl[o] = D3 ? 0.f : vpp[o * HL + n0 + i];
+          v4f c = {0, 0, 0, 0};
+          if (d0 < 4) {      // fan-in + bias fit one MFMA: k = q
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(X[(f_s0 + i) * LDK + q], w0p[(n0 + i) * LDK + q], c, 0, 0, 0);
+          } else {
+            c = mma<LDK, LDK>(X + f_s0 * LDK, w0p + n0 * LDK, KP, c, i, q);
+          }
+          c = relu4(c);
+          *(v4f *)(h1t + (n0 + i) * LS + f_s0 + 4 * q) = c;
+          if (D3) {
+            float *hp = h1 + (f_s0 + 4 * q) * LS + n0 + i;
+            hp[0] = c.x; hp[LS] = c.y; hp[2 * LS] = c.z; hp[3 * LS] = c.w;
+          } else {
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+              pr[o][0] = __builtin_fmaf(wl[o], c.x, pr[o][0]); pr[o][1] = __builtin_fmaf(wl[o], c.y, pr[o][1]);
+              pr[o][2] = __builtin_fmaf(wl[o], c.z, pr[o][2]); pr[o][3] = __builtin_fmaf(wl[o], c.w, pr[o][3]);
+            }
+          }
+        }
+        if (!D3 && w < ntl) {
+#pragma unroll
+          for (int o = 0; o < O; ++o) {
+            v4f sres;
+            sres.x = row_sum16(pr[o][0]); sres.y = row_sum16(pr[o][1]); sres.z = row_sum16(pr[o][2]); sres.w = row_sum16(pr[o][3]);
+            if (i == 0) *(v4f *)(red + ((w >> 2) * O + o) * LS + f_s0 + 4 * q) = sres;
+          }
         }
       }
       __syncthreads();
-      // ---- layer 1 (depth 3): h2[s][n] = relu(h1[s] . W1[n] + b1[n])
-      if (d3) {
+      STAMP(1);
+      // ---- layer 1 (two hidden layers): h2[s][n] = relu(h1[s] . W1[n] + b1[n]), the last layer's partial dots behind it
+      if (D3) {
         const int ntl = 4 * (H2 / 16);
-        for (int t0 = w; t0 < ntl; t0 += 2 * NW) {
+        for (int t0 = w; t0 < ntl; t0 += 2 * NW) {      // tiles t0 and t0 + NW: the same sample tile, two feature tiles
           const bool two = t0 + NW < ntl;
-          const int t1 = two ? t0 + NW : t0;
-          const int s0 = (t0 & 3) * 16, n0 = (t0 >> 2) * 16, n1 = (t1 >> 2) * 16;
+          const int n0 = (t0 >> 2) * 16, n1 = two ? ((t0 + NW) >> 2) * 16 : n0;
+          float wl0[O], wl1[O];
+#pragma unroll
+          for (int o = 0; o < O; ++o) { wl0[o] = vpp[o * HL + n0 + i]; wl1[o] = vpp[o * HL + n1 + i]; }
           const float bb0 = vpp[L.o_b1 + n0 + i], bb1 = vpp[L.o_b1 + n1 + i];
           v4f c0 = {bb0, bb0, bb0, bb0}, c1 = {bb1, bb1, bb1, bb1};
-          mma2<false, true>(h1t + s0, h1t + s0, LDS_S, w1 + n0 * ldw1, w1 + n1 * ldw1, ldw1, H1, c0, c1, i, q);
-          *(v4f *)(h2t + (n0 + i) * LDS_S + s0 + 4 * q) = relu4(c0);
-          if (two) *(v4f *)(h2t + (n1 + i) * LDS_S + s0 + 4 * q) = relu4(c1);
+          mma2<LS, LS>(h1 + f_s0 * LS, h1 + f_s0 * LS, w1 + n0 * LS, w1 + n1 * LS, H1, c0, c1, i, q);
+          c0 = relu4(c0);
+          c1 = relu4(c1);
+          *(v4f *)(h2t + (n0 + i) * LS + f_s0 + 4 * q) = c0;
+          if (two) *(v4f *)(h2t + (n1 + i) * LS + f_s0 + 4 * q) = c1;
+#pragma unroll
+          for (int o = 0; o < O; ++o) {
+            v4f s0r, s1r;
+            s0r.x = row_sum16(wl0[o] * c0.x); s0r.y = row_sum16(wl0[o] * c0.y); s0r.z = row_sum16(wl0[o] * c0.z); s0r.w = row_sum16(wl0[o] * c0.w);
+            s1r.x = row_sum16(wl1[o] * c1.x); s1r.y = row_sum16(wl1[o] * c1.y); s1r.z = row_sum16(wl1[o] * c1.z); s1r.w = row_sum16(wl1[o] * c1.w);
+            if (i == 0) {
+              *(v4f *)(red + ((n0 >> 4) * O + o) * LS + f_s0 + 4 * q) = s0r;
+              if (two) *(v4f *)(red + ((n1 >> 4) * O + o) * LS + f_s0 + 4 * q) = s1r;
+            }
+          }
         }
         __syncthreads();
       }
-      // ---- last layer: out[s][o] = bL[o] + wL[o] . h[s]; lane = sample, the waves split the features
-      {
-        const int nper = HL / NW, n0 = w * nper;
-        float pr[MAXO] = {0, 0, 0, 0};
-        for (int n = n0; n < n0 + nper; ++n) {
-          const float h = hlt[n * LDS_S + lane];
-#pragma unroll
-          for (int o = 0; o < MAXO; ++o)
-            if (o < O) pr[o] = __builtin_fmaf(vpp[L.o_wl + o * HL + n], h, pr[o]);
-        }
-#pragma unroll
-        for (int o = 0; o < MAXO; ++o)
-          if (o < O) red[(w * MAXO + o) * S + lane] = pr[o];
-      }
-      __syncthreads();
+      STAMP(2);
       // ---- loss and its derivative at the outputs (wave 0, lane = sample): k_ppo_loss's arithmetic
       if (w == 0) {
         const bool ok = lane < rows_t;
-        float out[MAXO];
+        float out[O];
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o) {
-          out[o] = 0.f;
-          if (o < O) {
-            float sacc = vpp[L.o_bl + o];
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) sacc += red[(ww * MAXO + o) * S + lane];
-            out[o] = sacc;
-          }
+        for (int o = 0; o < O; ++o) {
+          float sacc = vpp[L.o_bl + o];
+          for (int sl = 0; sl < L.nred; ++sl) sacc += red[(sl * O + o) * LS + lane];
+          out[o] = sacc;
         }
         if (role == 0) {      // critic: mse_loss(values, returns), weight alpha
           const float dv = out[0] - cur_ret;
@@ -378,224 +568,258 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           a_gb[0] += g;
           gout[lane] = g;
         } else {
-          const float gmin = -(1.0f / (float)((int64_t)bm * A));
+          const float gmin = -(1.0f / (float)((int64_t)bm * O));
 #pragma unroll
-          for (int a = 0; a < MAXO; ++a) {
-            if (a < A) {
-              const float sigma = expf(vpp[L.o_ls + a]);
-              const float var = sigma * sigma;
-              const float logsig = logf(sigma);
-              const float den = 2.0f * var;
-              const float d = cur_act[a] - out[a];
-              const float sq = d * d;
-              const float lp = ((-sq) / den - logsig) - LOG_SQRT_2PI;
-              const float ratio = expf(lp - cur_old[a]);
-              const float s1 = ratio * cur_adv;
-              const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
-              const float s2 = rc * cur_adv;
-              const float g1 = s1 < s2 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
-              const float g2 = s2 < s1 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
-              const bool inr = ratio >= P.lo && ratio <= P.hi;
-              const float g_ratio = g1 * cur_adv + (inr ? g2 * cur_adv : 0.f);
-              const float g_lp = g_ratio * ratio;
-              const float g = ok ? (g_lp / den) * (2.0f * d) : 0.f;
-              a_min += ok ? fminf(s1, s2) : 0.f;
-              a_ent += ok ? ENT_CONST + logsig : 0.f;
-              a_dls[a] += ok ? g_lp * (sq / var - 1.0f) : 0.f;
-              a_gb[a] += g;
-              gout[a * LDS_S + lane] = g;
-            }
+          for (int a = 0; a < O; ++a) {
+            const float sigma = expf(vpp[L.o_ls + a]);
+            const float var = sigma * sigma;
+            const float logsig = logf(sigma);
+            const float den = 2.0f * var;
+            const float d = cur_act[a] - out[a];
+            const float sq = d * d;
+            const float lp = ((-sq) / den - logsig) - LOG_SQRT_2PI;
+            const float ratio = expf(lp - cur_old[a]);
+            const float s1 = ratio * cur_adv;
+            const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
+            const float s2 = rc * cur_adv;
+            const float g1 = s1 < s2 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+            const float g2v = s2 < s1 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+            const bool inr = ratio >= P.lo && ratio <= P.hi;
+            const float g_ratio = g1 * cur_adv + (inr ? g2v * cur_adv : 0.f);
+            const float g_lp = g_ratio * ratio;
+            const float g = ok ? (g_lp / den) * (2.0f * d) : 0.f;
+            a_min += ok ? fminf(s1, s2) : 0.f;
+            a_ent += ok ? ENT_CONST + logsig : 0.f;
+            a_dls[a] += ok ? g_lp * (sq / var - 1.0f) : 0.f;
+            a_gb[a] += g;
+            gout[a * LS + lane] = g;
           }
         }
       }
       __syncthreads();
-      // ---- lane = feature: dwL[o][n] += sum_s gout[s][o] h[n][s];  g[n][s] = (sum_o gout[s][o] wL[o][n]) (h > 0), in place
+      STAMP(3);
+      // ---- lane = feature: dwL[o][n] += sum_s gout[s][o] h[n][s];  g[n][s] = (sum_o gout[s][o] wL[o][n]) (h > 0), written
+      // over h's image and (two hidden layers) as the [sample][feature] copy the next product sums over
       if (gp_on) {
-        float wl_n[MAXO];
+        float wl_n[O];
 #pragma unroll
-        for (int o = 0; o < MAXO; ++o) wl_n[o] = o < O ? vpp[L.o_wl + o * HL + gp_n] : 0.f;
+        for (int o = 0; o < O; ++o) wl_n[o] = vpp[o * HL + gp_n];
+#pragma unroll 2
         for (int s = gp_sr * gp_ns; s < (gp_sr + 1) * gp_ns; s += 4) {
-          v4f h = *(const v4f *)(hlt + gp_n * LDS_S + s);
+          const v4f h = *(const v4f *)(hlt + gp_n * LS + s);
           v4f g = {0, 0, 0, 0};
 #pragma unroll
-          for (int o = 0; o < MAXO; ++o) {
-            if (o < O) {
-              const v4f go = *(const v4f *)(gout + o * LDS_S + s);
-              dwl[o] = __builtin_fmaf(go.x, h.x, dwl[o]); dwl[o] = __builtin_fmaf(go.y, h.y, dwl[o]);
-              dwl[o] = __builtin_fmaf(go.z, h.z, dwl[o]); dwl[o] = __builtin_fmaf(go.w, h.w, dwl[o]);
-              g.x = __builtin_fmaf(go.x, wl_n[o], g.x); g.y = __builtin_fmaf(go.y, wl_n[o], g.y);
-              g.z = __builtin_fmaf(go.z, wl_n[o], g.z); g.w = __builtin_fmaf(go.w, wl_n[o], g.w);
-            }
+          for (int o = 0; o < O; ++o) {
+            const v4f go = *(const v4f *)(gout + o * LS + s);
+            dwl[o] = __builtin_fmaf(go.x, h.x, dwl[o]); dwl[o] = __builtin_fmaf(go.y, h.y, dwl[o]);
+            dwl[o] = __builtin_fmaf(go.z, h.z, dwl[o]); dwl[o] = __builtin_fmaf(go.w, h.w, dwl[o]);
+            g.x = __builtin_fmaf(go.x, wl_n[o], g.x); g.y = __builtin_fmaf(go.y, wl_n[o], g.y);
+            g.z = __builtin_fmaf(go.z, wl_n[o], g.z); g.w = __builtin_fmaf(go.w, wl_n[o], g.w);
           }
-          g.x = h.x > 0.f ? g.x : 0.f; g.y = h.y > 0.f ? g.y : 0.f; g.z = h.z > 0.f ? g.z : 0.f; g.w = h.w > 0.f ? g.w : 0.f;
-          db1 += (g.x + g.y) + (g.z + g.w);
-          *(v4f *)(hlt + gp_n * LDS_S + s) = g;
+          g = mask4(g, h);
+          *(v4f *)(hlt + gp_n * LS + s) = g;
+          if (D3) {
+            db1 += (g.x + g.y) + (g.z + g.w);
+            float *gp = g2 + s * LS + gp_n;
+            gp[0] = g.x; gp[LS] = g.y; gp[2 * LS] = g.z; gp[3 * LS] = g.w;
+          }
         }
       }
       __syncthreads();
-      if (d3) {
-        // ---- dW1[n][k] += sum_s g2[n][s] h1[k][s]  (both operands sample-contiguous)
-        {
-          const bool two = t_ok[1];
-          const int r0 = t_row[0], c0 = t_col[0], r1 = two ? t_row[1] : r0, c1 = two ? t_col[1] : c0;
-          if (t_ok[0]) {
-            v4f z = {0, 0, 0, 0};
-            mma2<true, true>(h2t + r0 * LDS_S, h2t + r1 * LDS_S, LDS_S, h1t + c0 * LDS_S, h1t + c1 * LDS_S, LDS_S, S,
-                             own[0].acc, two ? own[1].acc : z, i, q);
-          }
+      STAMP(4);
+      if (D3) {
+        // ---- dW1[n][k] += sum_s g2[n][s] h1[k][s]
+        if (T1 == 2 && own1[T1 - 1]) {
+          mma2<LS, LS>(h2t + r1[0] * LS, h2t + r1[T1 - 1] * LS, h1t + c1[0] * LS, h1t + c1[T1 - 1] * LS, S, acc1[0], acc1[T1 - 1], i, q);
+        } else {
+#pragma unroll
+          for (int u = 0; u < T1; ++u)
+            if (own1[u]) acc1[u] = mma<LS, LS>(h2t + r1[u] * LS, h1t + c1[u] * LS, S, acc1[u], i, q);
         }
-        __syncthreads();
-        // ---- g1[s][k] = (sum_n g2[s][n] W1[n][k]) (h1 > 0) as C[s][k] tiles, written over h1's image
+        STAMP(5);
+        // ---- g1[s][k] = (sum_n g2[s][n] W1[n][k]) (h1[s][k] > 0) as C[s][k] tiles -> [feature][sample] image
         {
           const int ntl = 4 * (H1 / 16);
           for (int t0 = w; t0 < ntl; t0 += 2 * NW) {
             const bool two = t0 + NW < ntl;
-            const int t1 = two ? t0 + NW : t0;
-            const int s0 = (t0 & 3) * 16, k0 = (t0 >> 2) * 16, k1 = (t1 >> 2) * 16;
+            const int k0 = (t0 >> 2) * 16, k1 = two ? ((t0 + NW) >> 2) * 16 : k0;
             v4f c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-            mma2<false, false>(h2t + s0, h2t + s0, LDS_S, w1 + k0, w1 + k1, ldw1, H2, c0, c1, i, q);
-            float *m0 = h1t + (k0 + i) * LDS_S + s0 + 4 * q, *m1 = h1t + (k1 + i) * LDS_S + s0 + 4 * q;
-            const v4f h0 = *(const v4f *)m0;
-            c0.x = h0.x > 0.f ? c0.x : 0.f; c0.y = h0.y > 0.f ? c0.y : 0.f; c0.z = h0.z > 0.f ? c0.z : 0.f; c0.w = h0.w > 0.f ? c0.w : 0.f;
-            *(v4f *)m0 = c0;
-            if (two) {
-              const v4f hh = *(const v4f *)m1;
-              c1.x = hh.x > 0.f ? c1.x : 0.f; c1.y = hh.y > 0.f ? c1.y : 0.f; c1.z = hh.z > 0.f ? c1.z : 0.f; c1.w = hh.w > 0.f ? c1.w : 0.f;
-              *(v4f *)m1 = c1;
-            }
+            mma2<LS, LS>(g2 + f_s0 * LS, g2 + f_s0 * LS, w1t + k0 * LS, w1t + k1 * LS, H2, c0, c1, i, q);
+            const int at0 = (k0 + i) * LS + f_s0 + 4 * q, at1 = (k1 + i) * LS + f_s0 + 4 * q;
+            *(v4f *)(g1t + at0) = mask4(c0, *(const v4f *)(h1t + at0));
+            if (two) *(v4f *)(g1t + at1) = mask4(c1, *(const v4f *)(h1t + at1));
           }
         }
         __syncthreads();
-        // ---- dW0'[n][j] += sum_s g1[n][s] x'[j][s]
-        if (t_ok[2]) {
-          v4f z = {0, 0, 0, 0};
-          mma2<true, true>(h1t + t_row[2] * LDS_S, h1t + t_row[2] * LDS_S, LDS_S, X, X, LDS_S, S, own[2].acc, z, i, q);
-        }
-      } else if (t_ok[0]) {
-        const bool two = t_ok[1];
-        const int r1 = two ? t_row[1] : t_row[0];
-        v4f z = {0, 0, 0, 0};
-        mma2<true, true>(h1t + t_row[0] * LDS_S, h1t + r1 * LDS_S, LDS_S, X, X, LDS_S, S, own[0].acc, two ? own[1].acc : z, i, q);
       }
-      // the next tile's x' image goes into the other buffer (nobody reads that one now); its loss inputs become current
-      if (more) {
-        store_x(xpt[cur ^ 1], nrows);
-        cur ^= 1;
-        cur_adv = in_adv; cur_ret = in_ret;
+      STAMP(6);
+      // ---- dW0'[n][j] += sum_s g1[n][s] x'[j][s]
+      if (T1 == 2 && own0[T1 - 1]) {
+        mma2<LS, LS>(g1t + w * 16 * LS, g1t + (w + NW) * 16 * LS, XT, XT, S, acc0[0], acc0[T1 - 1], i, q);
+      } else {
 #pragma unroll
-        for (int a = 0; a < MAXO; ++a) { cur_act[a] = in_act[a]; cur_old[a] = in_old[a]; }
+        for (int u = 0; u < T1; ++u)
+          if (own0[u]) acc0[u] = mma<LS, LS>(g1t + (w + NW * u) * 16 * LS, XT, S, acc0[u], i, q);
       }
+      STAMP(7);
+      // the next tile's x' images are in the other buffers (stored at the top of this tile); its loss inputs become current
+      if (more) {
+        cur ^= 1;
+        cur_adv = nxt_adv; cur_ret = nxt_ret;
+#pragma unroll
+        for (int a = 0; a < O; ++a) { cur_act[a] = nxt_act[a]; cur_old[a] = nxt_old[a]; }
+      }
+      STAMP(8);
       if (t + 1 < ntile) __syncthreads();
     }
+    const int t = 0;      // (for the stamps below)
+    (void)t;
 
-    // ---- the update.  Partial sums of the lane = feature pass, the loss values, the small vectors' gradients
+    // ---- the update.  Layer 0's gradient tile -> LDS (its state is spread one element per thread); partial sums of
+    // the lane = feature pass; the loss values and the gradients that come out of them.  (Two hidden layers: the
+    // partial sums lie over h1 / h1t and layer 0's gradient over h2t -- every wave is past the barrier behind the last
+    // product that reads those.)
+#pragma unroll
+    for (int u = 0; u < T1; ++u) {
+      if (own0[u]) {
+        float *gp = gw0 + ((w + NW * u) * 16 + 4 * q) * LDK + i;
+        gp[0] = acc0[u].x; gp[LDK] = acc0[u].y; gp[2 * LDK] = acc0[u].z; gp[3 * LDK] = acc0[u].w;
+        acc0[u] = (v4f){0, 0, 0, 0};
+      }
+    }
     if (gp_on) {
 #pragma unroll
-      for (int o = 0; o < MAXO; ++o)
-        if (o < O) part[(gp_sr * (MAXO + 1) + o) * L.HLP + gp_n] = dwl[o];
-      part[(gp_sr * (MAXO + 1) + MAXO) * L.HLP + gp_n] = db1;
+      for (int o = 0; o < O; ++o) part[(gp_sr * L.PO + o) * L.HLP + gp_n] = dwl[o];
+      if (D3) part[(gp_sr * L.PO + O) * L.HLP + gp_n] = db1;
     }
     if (w == 0) {
       if (role == 0) {
         const float s_crit = trl_wave_sum(a_crit), gb = trl_wave_sum(a_gb[0]);
         if (lane == 0) {
           P.losses[4 * k + 1] = s_crit * (1.0f / (float)bm);
-          vpg[L.o_bl] = gb;
+          tailg[0] = gb;
         }
       } else {
-        const float invBA = 1.0f / (float)((int64_t)bm * A);
+        const float invBA = 1.0f / (float)((int64_t)bm * O);
         const float s_min = trl_wave_sum(a_min), s_ent = trl_wave_sum(a_ent);
         if (lane == 0) {
           P.losses[4 * k + 0] = -(s_min * invBA);
           P.losses[4 * k + 2] = s_ent * invBA;
         }
 #pragma unroll
-        for (int a = 0; a < MAXO; ++a) {
-          if (a < A) {
-            const float gb = trl_wave_sum(a_gb[a]), gl = trl_wave_sum(a_dls[a]);
-            if (lane == 0) {
-              vpg[L.o_bl + a] = gb;
-              vpg[L.o_ls + a] = gl + (-P.beta / (float)A);      // the entropy term's share: d(-beta * mean(ent)) / d log_std[a]
-            }
+        for (int a = 0; a < O; ++a) {
+          const float gb = trl_wave_sum(a_gb[a]), gl = trl_wave_sum(a_dls[a]);
+          if (lane == 0) {
+            tailg[a] = gb;
+            tailg[L.o_ls - L.o_bl + a] = gl + (-P.beta / (float)O);      // the entropy term's share: d(-beta * mean(ent)) / d log_std[a]
           }
         }
       }
     }
     __syncthreads();
-    TrlAdamScalars sc;
-    sc.w1 = P.w1; sc.beta2 = P.beta2; sc.c2 = P.c2; sc.bc2_sqrt = bc2_sqrt; sc.eps = P.eps; sc.neg_step = neg_step;
-    sc.scale = 1.0f; sc.clip = P.clip;
+    STAMP(9);
+    // (by value, the per-step scalars made wave-uniform: the block must live in registers, not on the stack)
+    auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+    const AdamV sc = {P.w1, P.beta2, P.c2, P.eps, P.clip, uni(step_k.x), uni(step_k.z), uni(step_k.y)};
     const bool last = k + 1 == K;
-    for (int e = tid; e < L.NV; e += NT) {
+    // the small vectors, spread from the far end of the workgroup (layer 0's elements start at thread 0)
+    for (int e = NT - 1 - tid; e < L.NV; e += NT) {
       float g;
       if (e < L.o_bl) {
         const int o = e / HL, n = e - o * HL;
         g = 0.f;
-        for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * (MAXO + 1) + o) * L.HLP + n];
-      } else if (e >= L.o_b1 && e < L.o_ls) {
+        for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + o) * L.HLP + n];
+      } else if (D3 && e >= L.o_b1 && e < L.o_ls) {
         const int n = e - L.o_b1;
         g = 0.f;
-        for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * (MAXO + 1) + MAXO) * L.HLP + n];
+        for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + O) * L.HLP + n];
       } else {
-        g = vpg[e];
+        g = tailg[e - L.o_bl];
       }
       float p = vpp[e], m = vpm[e], v = vpv[e];
-      trl_adam_elem(&p, &g, &m, &v, sc);
-      vpp[e] = p; vpm[e] = m; vpv[e] = v; vpg[e] = g;
+      adam1(p, g, m, v, sc);
+      vpp[e] = p; vpm[e] = m; vpv[e] = v;
+      if (last) P.grad[vp_global(e)] = g;      // the gradients the last learn() leaves behind (after clip_grad_value_)
     }
+    STAMP(10);
+    // layer 0: the thread's elements four at a time (the clipped gradient goes back to gw0: the last update's is
+    // written out after the loop)
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
-      if (t_ok[sl]) {
-        v4f g;
-        adam4(own[sl], sc, g);
-        const float p[4] = {own[sl].p.x, own[sl].p.y, own[sl].p.z, own[sl].p.w};
-        const float gg[4] = {g.x, g.y, g.z, g.w};
+    for (int u4 = 0; u4 < U0; u4 += 4) {
+      if (tid + u4 * NT < n0e) {
+        float pp[4], gg[4];
+        int at[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = t_row[sl] + 4 * q + r, col = t_col[sl] + i;
-          if (t_is_w1[sl]) w1[row * ldw1 + col] = p[r];
-          else if (col <= d0) w0p[row * LDK + col] = p[r];
-          if (last) {      // the gradients the last learn() leaves behind (after clip_grad_value_)
-            int64_t go = -1;
-            if (t_is_w1[sl]) go = N.w_off[1] + (int64_t)row * H1 + col;
-            else if (col < d0) go = N.w_off[0] + (int64_t)row * d0 + col;
-            else if (col == d0) go = N.b_off[0] + row;
-            if (go >= 0) P.grad[go] = gg[r];
+        for (int u = 0; u < 4; ++u) {
+          const int e = tid + (u4 + u) * NT, ec = e < n0e ? e : tid;
+          at[u] = (ec >> 4) * LDK + (ec & 15);
+          pp[u] = w0p[at[u]]; gg[u] = gw0[at[u]];
+        }
+        v4f p4 = {pp[0], pp[1], pp[2], pp[3]}, g4 = {gg[0], gg[1], gg[2], gg[3]};
+        v4f m4 = {m0[u4], m0[u4 + 1], m0[u4 + 2], m0[u4 + 3]}, v4 = {v0[u4], v0[u4 + 1], v0[u4 + 2], v0[u4 + 3]};
+        adam4(p4, g4, m4, v4, sc);
+        const float po[4] = {p4.x, p4.y, p4.z, p4.w}, go[4] = {g4.x, g4.y, g4.z, g4.w}, mo[4] = {m4.x, m4.y, m4.z, m4.w},
+                    vo[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (tid + (u4 + u) * NT < n0e) {
+            w0p[at[u]] = po[u]; gw0[at[u]] = go[u];
+            m0[u4 + u] = mo[u]; v0[u4 + u] = vo[u];
           }
         }
       }
     }
+    STAMP(11);
+#pragma unroll
+    for (int u = 0; u < T1; ++u) {
+      if (own1[u]) {
+        float *wp = w1 + (r1[u] + 4 * q) * LS + c1[u] + i;
+        v4f p4 = {wp[0], wp[LS], wp[2 * LS], wp[3 * LS]};
+        adam4(p4, acc1[u], m1[u], v1[u], sc);
+        wp[0] = p4.x; wp[LS] = p4.y; wp[2 * LS] = p4.z; wp[3 * LS] = p4.w;
+        *(v4f *)(w1t + (c1[u] + i) * LS + r1[u] + 4 * q) = p4;
+        if (!last) acc1[u] = (v4f){0, 0, 0, 0};      // (the last update's clipped gradient is written out after the loop)
+      }
+    }
+    STAMP(12);
     __syncthreads();
+    STAMP(13);
   }
 
-  // ---- parameters and moments back to the flat buffers
+  // ---- parameters, moments and the last update's clipped gradients (what the last learn() leaves in .grad) back to the
+  // flat buffers
 #pragma unroll
-  for (int sl = 0; sl < 3; ++sl) {
-    if (t_ok[sl]) {
-      const float p[4] = {own[sl].p.x, own[sl].p.y, own[sl].p.z, own[sl].p.w};
-      const float m[4] = {own[sl].m.x, own[sl].m.y, own[sl].m.z, own[sl].m.w};
-      const float v[4] = {own[sl].v.x, own[sl].v.y, own[sl].v.z, own[sl].v.w};
+  for (int u = 0; u < T1; ++u) {
+    if (own1[u]) {
+      const float m[4] = {m1[u].x, m1[u].y, m1[u].z, m1[u].w}, v[4] = {v1[u].x, v1[u].y, v1[u].z, v1[u].w},
+                  gl[4] = {acc1[u].x, acc1[u].y, acc1[u].z, acc1[u].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = t_row[sl] + 4 * q + r, col = t_col[sl] + i;
-        int64_t g = -1;
-        if (t_is_w1[sl]) g = N.w_off[1] + (int64_t)row * H1 + col;
-        else if (col < d0) g = N.w_off[0] + (int64_t)row * d0 + col;
-        else if (col == d0) g = N.b_off[0] + row;
-        if (g >= 0) { P.param[g] = p[r]; P.m[g] = m[r]; P.v[g] = v[r]; }
+        const int64_t g = N.w_off[1] + (int64_t)(r1[u] + 4 * q + r) * H1 + c1[u] + i;
+        P.param[g] = w1[(r1[u] + 4 * q + r) * LS + c1[u] + i]; P.m[g] = m[r]; P.v[g] = v[r]; P.grad[g] = gl[r];
       }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U0; ++u) {
+    const int e = tid + u * NT;
+    if (e < n0e) {
+      const int64_t g = w0_global(e);
+      const int at = (e >> 4) * LDK + (e & 15);
+      if (g >= 0) { P.param[g] = w0p[at]; P.m[g] = m0[u]; P.v[g] = v0[u]; P.grad[g] = gw0[at]; }
     }
   }
   for (int e = tid; e < L.NV; e += NT) {
     const int64_t g = vp_global(e);
-    P.param[g] = vpp[e]; P.m[g] = vpm[e]; P.v[g] = vpv[e]; P.grad[g] = vpg[e];
+    P.param[g] = vpp[e]; P.m[g] = vpm[e]; P.v[g] = vpv[e];
   }
 }
 
+template <bool D3, int AO>
 __global__ __launch_bounds__(NT) void k_ppo_epoch(const Args P) {
   extern __shared__ __align__(16) float lds[];
-  if (blockIdx.x == 0) epoch_body<0>(P, lds);
-  else epoch_body<1>(P, lds);
+  if (blockIdx.x == 0) epoch_body<0, D3, 1>(P, lds);
+  else epoch_body<1, D3, AO>(P, lds);
 }
 
 constexpr int64_t MAX_LDS_BYTES = 160 * 1024;
@@ -629,11 +853,83 @@ int fill_net(const char *fn, const char *name, const trl_mlp_desc *d, const trl_
   return TRL_OK;
 }
 
+typedef void (*EpochKernel)(const Args);
+
+EpochKernel pick_kernel(bool d3, int A) {
+  switch (A) {
+    case 1: return d3 ? k_ppo_epoch<true, 1> : k_ppo_epoch<false, 1>;
+    case 2: return d3 ? k_ppo_epoch<true, 2> : k_ppo_epoch<false, 2>;
+    case 3: return d3 ? k_ppo_epoch<true, 3> : k_ppo_epoch<false, 3>;
+    default: return d3 ? k_ppo_epoch<true, 4> : k_ppo_epoch<false, 4>;
+  }
+}
+
 }  // namespace
+
+#ifdef TRL_TUNING
+namespace {
+// diagnostic build: the fast Adam of this file against trl_adam_elem on caller-supplied elements; counts elements whose
+// parameter, clipped gradient or moments differ in any bit
+__global__ void k_adam_compare(const float *p, const float *g, const float *m, const float *v, int64_t n, TrlAdamScalars ref,
+                               AdamV fast, unsigned long long *mismatch) {
+  const int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (e0 + 3 >= n) return;
+  v4f p4 = {p[e0], p[e0 + 1], p[e0 + 2], p[e0 + 3]}, g4 = {g[e0], g[e0 + 1], g[e0 + 2], g[e0 + 3]};
+  v4f m4 = {m[e0], m[e0 + 1], m[e0 + 2], m[e0 + 3]}, v4 = {v[e0], v[e0 + 1], v[e0 + 2], v[e0 + 3]};
+  adam4(p4, g4, m4, v4, fast);
+  const float pf[4] = {p4.x, p4.y, p4.z, p4.w}, gf[4] = {g4.x, g4.y, g4.z, g4.w}, mf[4] = {m4.x, m4.y, m4.z, m4.w},
+              vf[4] = {v4.x, v4.y, v4.z, v4.w};
+  unsigned bad = 0;
+  for (int r = 0; r < 4; ++r) {
+    float pr = p[e0 + r], gr = g[e0 + r], mr = m[e0 + r], vr = v[e0 + r];
+    trl_adam_elem(&pr, &gr, &mr, &vr, ref);
+    bad += __builtin_bit_cast(unsigned, pr) != __builtin_bit_cast(unsigned, pf[r]) ||
+           __builtin_bit_cast(unsigned, gr) != __builtin_bit_cast(unsigned, gf[r]) ||
+           __builtin_bit_cast(unsigned, mr) != __builtin_bit_cast(unsigned, mf[r]) ||
+           __builtin_bit_cast(unsigned, vr) != __builtin_bit_cast(unsigned, vf[r]);
+  }
+  if (bad) atomicAdd(mismatch, (unsigned long long)bad);
+}
+}  // namespace
+
+extern "C" int trl_tune_adam_compare(const float *p, const float *g, const float *m, const float *v, int64_t n, double lr,
+                                     double beta1, double beta2, double eps, int64_t step, double clip_value,
+                                     unsigned long long *mismatch_d, void *stream) {
+  const TrlAdamScalars ref = trl_adam_scalars(lr, beta1, beta2, eps, step, 1.0, clip_value);
+  AdamV f;
+  f.w1 = ref.w1; f.beta2 = ref.beta2; f.c2 = ref.c2; f.eps = ref.eps;
+  f.clip = clip_value > 0 ? (float)clip_value : __builtin_inff();
+  f.c = ref.bc2_sqrt; f.rc = (float)(1.0 / (double)ref.bc2_sqrt); f.neg_step = ref.neg_step;
+  hipLaunchKernelGGL(k_adam_compare, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, ref,
+                     f, mismatch_d);
+  return hipGetLastError() == hipSuccess ? TRL_OK : TRL_EHIP;
+}
+
+extern "C" int trl_tune_epoch_stamps(unsigned long long *out_h /*[2][16]*/) {
+  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_epoch_stamp), sizeof(unsigned long long) * 32) == hipSuccess ? TRL_OK : TRL_EHIP;
+}
+#endif
 
 extern "C" int64_t trl_ppo_learn_epoch_workspace_bytes(int64_t n_rows, int64_t minibatch, int32_t n_epochs) {
   if (n_rows <= 0 || minibatch <= 0 || n_epochs <= 0) return 0;
-  return ((n_rows + minibatch - 1) / minibatch) * n_epochs * 2 * (int64_t)sizeof(float);
+  return ((n_rows + minibatch - 1) / minibatch) * n_epochs * 4 * (int64_t)sizeof(float);
+}
+
+// 1 when trl_ppo_learn_epoch takes these networks (shapes and the LDS they need), 0 otherwise; no error text is set
+extern "C" int trl_ppo_learn_epoch_supported(const trl_mlp_desc *critic, const trl_mlp_desc *actor, int32_t A) {
+  if (!critic || !actor || A < 1 || A > MAXO || critic->depth != actor->depth) return 0;
+  Net n[2];
+  const trl_mlp_desc *d[2] = {critic, actor};
+  for (int r = 0; r < 2; ++r) {
+    const int dep = d[r]->depth;
+    if (dep != 2 && dep != 3) return 0;
+    n[r].depth = dep; n[r].d0 = d[r]->dims[0]; n[r].H1 = d[r]->dims[1]; n[r].H2 = dep == 3 ? d[r]->dims[2] : 0;
+    n[r].O = d[r]->dims[dep]; n[r].ls_off = r == 1 ? 0 : -1;
+    if (n[r].O != (r == 0 ? 1 : A) || n[r].d0 < 1 || n[r].d0 > KP - 1 || n[r].H1 < 16 || n[r].H1 % 16 || n[r].H1 > 256) return 0;
+    if (dep == 3 && (n[r].H2 < 16 || n[r].H2 % 16 || n[r].H1 > 64 || n[r].H2 > 64)) return 0;
+    if ((int64_t)make_lay(n[r]).total * 4 > MAX_LDS_BYTES) return 0;
+  }
+  return n[0].d0 == n[1].d0 ? 1 : 0;
 }
 
 extern "C" int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
@@ -652,11 +948,13 @@ extern "C" int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_des
   TRL_REQUIRE(minibatch <= 4096, "%s: minibatch %lld: this entry is for small minibatches (<= 4096); larger ones are "
               "trl_ppo_learn_fused's", fn, (long long)minibatch);
   TRL_REQUIRE(obs && action && returns && old_logp && adv && losses_out && log_std && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(((uintptr_t)ws & 15) == 0, "%s: the workspace must be 16 B aligned", fn);
   Args P = {};
   int rc;
   if ((rc = fill_net(fn, "critic", critic, adam, 1, P.net[0])) || (rc = fill_net(fn, "actor", actor, adam, A, P.net[1])))
     return rc;
   TRL_REQUIRE(P.net[0].d0 == P.net[1].d0, "%s: critic and actor must see the same observation", fn);
+  TRL_REQUIRE(P.net[0].depth == P.net[1].depth, "%s: critic and actor must have the same depth", fn);
   const int64_t lo = log_std - adam->param;
   TRL_REQUIRE(lo >= 0 && lo + A <= adam->n, "%s: log_std must lie inside the optimizer's flat buffer", fn);
   P.net[1].ls_off = lo;
@@ -673,14 +971,15 @@ extern "C" int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_des
   P.obs = obs; P.action = action; P.returns = returns; P.old_logp = old_logp; P.adv = adv;
   P.n_rows = n_rows; P.B = (int)minibatch; P.n_epochs = n_epochs; P.A = A;
   P.lo = (float)(1.0 - clip); P.hi = (float)(1.0 + clip); P.alpha = (float)alpha; P.beta = (float)beta;
-  P.clip = (float)adam->clip_value;
+  P.clip = adam->clip_value > 0 ? (float)adam->clip_value : __builtin_inff();
   P.w1 = (float)(1.0 - adam->beta1); P.beta2 = (float)adam->beta2; P.c2 = (float)(1.0 - adam->beta2); P.eps = (float)adam->eps;
   P.steps = (const float *)ws;
   P.losses = losses_out;
   hipStream_t st = (hipStream_t)stream;
   const int K = (int)K64;
+  EpochKernel kern = pick_kernel(P.net[0].depth == 3, A);
   if (lds_bytes > 48 * 1024 &&      // (per device and cheap: set whenever the launch needs more than the default limit)
-      hipFuncSetAttribute((const void *)k_ppo_epoch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess) {
+      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess) {
     (void)hipGetLastError();
     trl_set_error("%s: could not raise the kernel's LDS limit", fn);
     return TRL_EHIP;
@@ -688,7 +987,7 @@ extern "C" int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_des
   hipLaunchKernelGGL(k_epoch_prep, dim3((K + 255) / 256), dim3(256), 0, st, (float *)ws, K, adam->lr, adam->beta1, adam->beta2,
                      adam->eps, adam->step);
   TRL_CHECK_LAUNCH(fn);
-  hipLaunchKernelGGL(k_ppo_epoch, dim3(2), dim3(NT), (size_t)lds_bytes, st, P);
+  hipLaunchKernelGGL(kern, dim3(2), dim3(NT), (size_t)lds_bytes, st, P);
   TRL_CHECK_LAUNCH(fn);
   hipLaunchKernelGGL(k_epoch_totals, dim3((K + 255) / 256), dim3(256), 0, st, losses_out, K, P.alpha, P.beta);
   TRL_CHECK_LAUNCH(fn);

@@ -857,7 +857,10 @@ class FusedPpoLearn:
     return True
 
   def epoch_supported(self):
-    return FusedPpoLearn.epoch_supports(self.critic_lin, self.actor_lin, self.log_std)
+    if not FusedPpoLearn.epoch_supports(self.critic_lin, self.actor_lin, self.log_std):
+      return False
+    C = self._C      # the library has the last word (LDS budget of the two workgroups)
+    return bool(_lib.lib().trl_ppo_learn_epoch_supported(C.byref(self.descs[0]), C.byref(self.descs[1]), self.A))
 
   def learn_epoch(self, obs, action, returns, old_logp, adv, minibatch, n_epochs, clip, alpha, beta, adam):
     """K = n_epochs * ceil(n / minibatch) consecutive learn() steps over the consecutive row ranges of the columns
