@@ -412,6 +412,17 @@ def bench_ppo(args, rank, world, dev):
   cols = keep['cols']
   if rank == 0 and world == 1 and not args.no_sweep:
     res['minibatch_sweep'] = minibatch_sweep(args, ctl, cols, n, ms_return, learn_slice, B, dt / steps * 1e3)
+    if args.hidden != '256':
+      # the same loop on the REFERENCE's own network (one hidden layer of 256, ppo_controller.py:14) at its own minibatch
+      torch.manual_seed(0)
+      ref_ctl = PPOController(3, 1, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3, clip_ratio=0.2, max_grad_norm=1.0,
+                              device=dev, hidden=(256,))
+      if ref_ctl._epoch is not None:
+        res['learn_epoch_reference_net'] = [
+            dict(minibatch=Bm, **learn_epoch_row(args, ref_ctl, cols, n, Bm, ms_return, (n + Bm - 1) // Bm,
+                                                 note='ActorCriticNet(3, 1, 256), the network PPOController builds by default; '
+                                                      'compute_return time taken from the headline run'))
+            for Bm in (64, 32)]
   if ctl._fused is not None:
     res['learn_kernel'] = learn_kernel_roofline(args, ctl, cols, min(B, n))
   return res, dict(T=T, hidden=hidden, B=B, epochs=args.epochs)
@@ -444,6 +455,8 @@ def minibatch_sweep(args, ctl, cols, n, ms_return, learn_slice, B_default, ms_de
     tps = args.epochs * n / (ms_step * 1e-3)
     row = {'minibatch': Bm, 'learn_calls_per_step': args.epochs * calls_per_epoch, 'ms_per_step': round(ms_step, 3),
            'transitions_per_sec': round(tps, 1), 'unique_transitions_per_sec': round(tps / args.epochs, 1), 'timed': timed}
+    if Bm < 4096 and getattr(ctl, '_epoch', None) is not None:
+      row['learn_epoch'] = learn_epoch_row(args, ctl, cols, n, Bm, ms_return, calls_per_epoch)
     if per_call is not None:
       row['us_per_learn_call'] = round(per_call * 1e3, 2)
       if Bm < 4096 and ctl._fused is not None:
@@ -458,6 +471,37 @@ def minibatch_sweep(args, ctl, cols, n, ms_return, learn_slice, B_default, ms_de
                         % ((Bm + 31) // 32, (Bm + 31) // 32))
     out.append(row)
   return out
+
+
+def learn_epoch_row(args, ctl, cols, n, Bm, ms_return, calls_per_epoch, note=None):
+  """The reference's minibatch loop (examples/ppo.py:66-73) as ONE persistent launch, PPOController.learn_epoch
+  (csrc/trl_epoch.hip): timed on a bounded run of consecutive minibatches (one launch), the 4-epoch step extrapolated
+  exactly as the learn()-per-minibatch row beside it."""
+  K = min(calls_per_epoch, 8192)
+  o, a, r, l, ad = (c[:K * Bm] for c in cols)
+  ds = [o, a, None, None, None, r, l, ad]
+  ctl.learn_epoch(ds, Bm, 1)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  e0.record()
+  ctl.learn_epoch(ds, Bm, 1)
+  e1.record()
+  torch.cuda.synchronize()
+  wall = (time.perf_counter() - t0) / K * 1e3          # ms per minibatch, host included
+  dev_us = e0.elapsed_time(e1) * 1e3 / K
+  ms_step = ms_return + args.epochs * calls_per_epoch * wall
+  tps = args.epochs * n / (ms_step * 1e-3)
+  row = {'ms_per_step': round(ms_step, 3), 'transitions_per_sec': round(tps, 1),
+         'unique_transitions_per_sec': round(tps / args.epochs, 1), 'us_per_minibatch': round(wall * 1e3, 3),
+         'us_gpu_per_minibatch': round(dev_us, 3),
+         'timed': 'one launch over %d consecutive minibatches of %d (k_ppo_epoch: two persistent workgroups, critic and actor), '
+                  'step extrapolated' % (K, Bm),
+         'bound': 'one CU per network: exact-f32 MFMA products of a 64-sample tile + clip/Adam of every parameter, each update '
+                  'waiting for the one before (DESIGN.md section 5)'}
+  if note:
+    row['note'] = note
+  return row
 
 
 def learn_kernel_roofline(args, ctl, cols, Bk):

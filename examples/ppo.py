@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from torchrl_amd.experiments import BaseExperiment  # noqa: E402
 from torchrl_amd.contrib.controllers import PPOController  # noqa: E402
-from torchrl_amd.utils.rollout import RolloutBuffer, env_major, iter_minibatches  # noqa: E402
+from torchrl_amd.utils.rollout import RolloutBuffer, env_major  # noqa: E402
 
 
 class PPOExperiment(BaseExperiment):
@@ -37,11 +37,13 @@ class PPOExperiment(BaseExperiment):
         obs, action, reward, last_next_obs, done[-1], done=done, masked=self.mask_dones, env_major_out=True)
     cols = [env_major(obs), env_major(action), returns.reshape(-1, 1), env_major(log_probs), adv.reshape(-1, 1)]
     self.rollout.truncate()
-    train_info = dict()
-    for _ in range(self.n_epochs):
-      for o, a, r, lp, ad in iter_minibatches(cols, self.batch_size):
-        train_info = self.controller.learn(o, a, None, None, None, r, lp, ad)
-    return train_info
+    # the reference's `for epoch: for minibatch in loader: controller.learn(*minibatch)` (examples/ppo.py:70-73) as one
+    # launch: learn_epoch walks the consecutive minibatches of every epoch with the weights resident on the CU (it runs
+    # the loop of learn() calls itself where the networks are outside the kernel's shapes); the logged values are the
+    # last minibatch's, as the reference's loop leaves them
+    o, a, r, lp, ad = cols
+    info = self.controller.learn_epoch([o, a, None, None, None, r, lp, ad], self.batch_size, self.n_epochs)
+    return {k: v[-1] for k, v in info.items()}
 
 
 if __name__ == '__main__':

@@ -60,29 +60,31 @@ def test_ppo_and_a2c_exp_through_whole_step_kernel():
   from ppo import PPOExperiment
   from a2c import A2CExperiment
   from torchrl_amd import functional as F
-  calls = {'learn': 0, 'a2c': 0, 'fwd': 0}
-  orig = (F.FusedPpoLearn.__call__, F.FusedPpoLearn.a2c, F.FusedPpoLearn.forward)
+  calls = {'learn': 0, 'a2c': 0, 'fwd': 0, 'epoch': 0}
+  orig = (F.FusedPpoLearn.__call__, F.FusedPpoLearn.a2c, F.FusedPpoLearn.forward, F.FusedPpoLearn.learn_epoch)
 
   def count(key, fn):
     def wrapped(self, *a, **k):
       calls[key] += 1
       return fn(self, *a, **k)
     return wrapped
-  F.FusedPpoLearn.__call__, F.FusedPpoLearn.a2c, F.FusedPpoLearn.forward = (
-      count('learn', orig[0]), count('a2c', orig[1]), count('fwd', orig[2]))
+  F.FusedPpoLearn.__call__, F.FusedPpoLearn.a2c, F.FusedPpoLearn.forward, F.FusedPpoLearn.learn_epoch = (
+      count('learn', orig[0]), count('a2c', orig[1]), count('fwd', orig[2]), count('epoch', orig[3]))
   try:
     exp = PPOExperiment(env_id='Pendulum-v0', n_envs=256, n_frames=256 * 8 * 2, rollout_steps=8, lmbda=0.95,
                         batch_size=512, n_epochs=2, seed=0)
     exp.run()
     assert exp.controller._fused is not None and exp._cur_frames == 256 * 8 * 2
-    assert calls['learn'] == 2 * 2 * 4 and calls['fwd'] >= 4      # 2 rollouts x 2 epochs x 4 minibatches
+    # 2 rollouts: each rollout's 2 epochs x 4 minibatches are ONE learn_epoch launch (examples/ppo.py -> PPOController.learn_epoch)
+    assert calls['epoch'] == 2 and calls['learn'] == 0 and calls['fwd'] >= 4
+    assert exp.controller.ac_net_optim.step_count == 2 * 2 * 4
     assert all(torch.isfinite(exp.logger.last['train/' + k][0]).item() for k in ('actor_loss', 'critic_loss'))
     exp = A2CExperiment(env_id='CartPole-v1', n_envs=256, n_frames=256 * 5 * 2, rollout_steps=5, seed=0)
     exp.run()
     assert exp.controller._fused is not None and calls['a2c'] == 2
     assert torch.isfinite(exp.logger.last['train/critic_loss'][0]).item()
   finally:
-    F.FusedPpoLearn.__call__, F.FusedPpoLearn.a2c, F.FusedPpoLearn.forward = orig
+    F.FusedPpoLearn.__call__, F.FusedPpoLearn.a2c, F.FusedPpoLearn.forward, F.FusedPpoLearn.learn_epoch = orig
 
 
 def test_rollout_buffer_matches_per_env_reference_path():
