@@ -85,9 +85,9 @@ def test_polyak_modules_and_random_controller():
 
 def test_record_layouts():
   cart = _Layout([(4,), (1,), (1,), (4,), (1,)], [torch.float32] * 5)
-  assert cart.stride == 44 and cart.offsets == [0, 16, 20, 24, 40]
+  assert cart.payload == 44 and cart.stride == 64 and cart.offsets == [0, 16, 20, 24, 40]      # narrow records: padded to one 64 B request
   pend = _Layout([(3,), (1,), (1,), (3,), (1,)], [torch.float32] * 5)
-  assert pend.stride == 36
+  assert pend.payload == 36 and pend.stride == 64
   atari = _Layout([(84, 84, 4), (1,), (1,), (84, 84, 4), (1,)],
                   [torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32])
   assert atari.col_bytes[0] == 28224 and atari.stride % 16 == 0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from the rocprofv3 --pmc passes of tools/profile_entries.sh: per bench entry
+"""profiles/r0N_pmc_traffic.json from the rocprofv3 --pmc passes of tools/profile_entries.sh: per bench entry
 (`bench.py --only <entry>`), the HBM bytes per launch of that entry's kernel.  FETCH_SIZE and WRITE_SIZE cannot
 share a pass (MI355X_MICROARCH.md, TCC counter budget), hence two files per entry.
 
@@ -34,8 +34,14 @@ def main():
     w, nw = mean_counter(wpath, 'WRITE_SIZE', kernel) if os.path.exists(wpath) else (None, 0)
     if f is None or w is None:
       continue
+    # The x2 of the guide is for 128 B requests of wide streaming reads tallied at 64 B.  The narrow gather's reads are
+    # single 64 B requests (one padded record each): its raw count is already bytes -- calibrated in round 3 on records
+    # padded to 64 B, where 65,536 random rows fetch 4.48 MB raw = 64 B per row + the 0.5 MB of indices
+    # (tools/narrow_pad_experiment.sh); doubled, that launch would have fetched twice what it can touch.
+    narrow = entry.startswith('gather_narrow')
     res[entry] = {'FETCH_SIZE_bytes_raw': f, 'fetch_bytes_corrected_x2': 2 * f, 'WRITE_SIZE_bytes': w,
-                  'hbm_bytes': 2 * f + w, 'launches': min(nf, nw), 'kernel': kernel,
+                  'hbm_bytes': (f if narrow else 2 * f) + w, 'fetch_correction': 'none (64 B requests)' if narrow else 'x2 (128 B requests tallied at 64 B)',
+                  'launches': min(nf, nw), 'kernel': kernel,
                   'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --only %s --kernel-iters 6`' % entry}
   json.dump(res, open(out, 'w'), indent=1)
   print(json.dumps({k: int(v['hbm_bytes']) for k, v in res.items()}, indent=1))

@@ -2,12 +2,12 @@
 # Per-configuration rocprofv3 evidence for bench.py's roofline entries (run on the GPU box):
 #   one --kernel-trace --stats run per entry (the process holds that entry's launches and nothing else), then two
 #   --pmc passes (FETCH_SIZE, WRITE_SIZE: they cannot share a pass) for the HBM-bound entries.
-# Output: gpurun_out/prof_r02/<entry>_kernel_stats.csv, <entry>_fetch.csv, <entry>_write.csv; copy the kernel
+# Output: gpurun_out/prof_r03/ (TRL_PROF_ROUND names the round)/<entry>_kernel_stats.csv, <entry>_fetch.csv, <entry>_write.csv; copy the kernel
 # stats into profiles/ and run tools/pmc_traffic.py over the counter files.
 #   bash tools/profile_entries.sh [entry ...]
 set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
-OUT="$ROOT/gpurun_out/prof_r02"
+OUT="$ROOT/gpurun_out/prof_${TRL_PROF_ROUND:-r03}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ENTRIES=("$@")
