@@ -84,6 +84,9 @@ def parse(argv=None):
                   help='off-policy loops: keep the BLAS default kernel picks (default: PyTorch TunableOp chooses per shape)')
   ap.add_argument('--f32-frames', action='store_true',
                   help='dqn_atari: gather the uint8 frames as float32 (the path before the uint8 first layer)')
+  ap.add_argument('--in-place', action='store_true',
+                  help='dqn_atari: read the sampled frames in place out of the ring (learn_indexed(in_place=True)) instead of '
+                       'gathering a dense batch first; bit-identical results, measured slower')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -719,7 +722,17 @@ def bench_offpolicy(args, rank, world, dev, atari):
     row_bytes, name = 36, 'ddpg_pendulum'
     wl = 'ddpg: %d-row Pendulum-shaped f32 replay per GPU, actor/critic MLP 256x256' % cap
 
-  if args.sampler == 'device':
+  in_place = atari and not args.f32_frames and args.in_place
+  if in_place:
+    # --in-place: the sampled frames are read where the ring holds them (DQNController.learn_indexed(in_place=True): the
+    # gather as the first layer's operand fetch).  Measured slower than the gathered batch, hence opt-in
+    if args.sampler == 'device':
+      def step():
+        ctl.learn_indexed(ds, ds.sample_indices_device(B), in_place=True)
+    else:
+      def step():
+        ctl.learn_indexed(ds, ds.sample_indices(B), in_place=True)
+  elif args.sampler == 'device':
     def step():
       ctl.learn(*ds.sample_device(B))   # Philox sampler kernel + HIP gather + fused loss/update, no host RNG work
   else:
@@ -750,7 +763,8 @@ def bench_offpolicy(args, rank, world, dev, atari):
                  'parallelism': 'dp%d' % world, 'name': name,
                  'gemm_selection': 'blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)',
                  'learn_step': 'hip-graph replay' if args.use_graph else
-                 (('eager, whole step in %d launches (csrc/trl_offpolicy.hip)' % (9 if not args.f32_frames else 6)) if atari
+                 (('eager, whole step in %d launches (csrc/trl_offpolicy.hip)%s' % (9 if not args.f32_frames else 6,
+                   '; frames read in place out of the ring (learn_indexed: no gathered batch)' if in_place else '')) if atari
                   else 'eager, the 10 phases of the step in ONE launch (k_chain, csrc/trl_offpolicy.hip)'
                   if getattr(ctl, '_fused', None) is not None else 'eager')},
       'roofline': roof,

@@ -28,9 +28,9 @@ class DQNExperiment(BaseExperiment):
   def train(self):
     if len(self.buffer) < self.batch_size:
       return {}
-    # == buffer[torch.randperm(len(buffer))[:batch_size]] (reference dqn.py:40-41): same indices,
-    # same generator state afterwards, batch already on the device
-    return self.controller.learn(*self.buffer.sample(self.batch_size))
+    # == controller.learn(*buffer[torch.randperm(len(buffer))[:batch_size]]) (reference dqn.py:40-42): same indices, same
+    # generator state afterwards (learn_indexed(..., in_place=True) would read uint8 frames where the ring holds them)
+    return self.controller.learn_indexed(self.buffer, self.buffer.sample_indices(self.batch_size))
 
 
 if __name__ == '__main__':

@@ -452,7 +452,7 @@ int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_desc *critic, 
 void trl_offpolicy_set_chain(int32_t on);
 
 /* DQNController.learn up to the optimizer step (dqn_controller.py:61-83; the periodic hard sync
- * of :85-86 stays trl_polyak with tau = 1) as 6 launches: q_net(obs), target_net(next_obs) and, for
+ * of :85-86 stays trl_polyak with tau = 1) as 6 launches (the uint8 variant below: 9): q_net(obs), target_net(next_obs) and, for
  * Double-DQN, q_net(next_obs) (QNet, models.py:6-24); the TD target and loss (trl_td_loss); the
  * backward into q_net; Adam.  Same network / batch limits as above; action [B] holds the index as
  * f32.  loss_out[0] = td loss.  opt->step == 0: gradients only. */
@@ -473,6 +473,25 @@ int trl_dqn_learn_fused_u8(const trl_mlp_desc *q_net, const trl_mlp_desc *target
                            const float *action, const float *reward, const uint8_t *next_obs, const float *done,
                            int64_t B, double gamma, int32_t double_dqn, int32_t kind, double huber_delta,
                            float *loss_out, const trl_adam_args *opt, void *ws, void *stream);
+
+/* The same step with the sampled frames read IN PLACE: `[b.to(device) for b in buffer[b_idx]]` + `controller.learn(...)`
+ * (examples/dqn.py:40-42) without the copy -- the first layer of all passes and its weight gradient read row b's two
+ * uint8 frames at their place in the replay ring (record (head + idx[b]) % capacity), so the 2 x 28 KB per sampled
+ * transition move once, as the layer's operand fetch, instead of being gathered into a dense batch first and read
+ * again.  A small prologue launch resolves the records and gathers the 12 B action / reward / done tail.
+ *   ring / capacity / stride / layout / head / count: the ring as trl_gather_rows takes it; the layout must be a
+ *   Transition (storage.py:51-57): columns obs, action, reward, next_obs, done with obs / next_obs stored TRL_U8,
+ *   dims[0] bytes wide at 16 B-aligned offsets, the other three one TRL_F32 each; stride % 16 == 0; capacity < 2^31.
+ *   idx: int64 [B] logical rows (0 = oldest), device memory or pinned host memory the device can read; values are
+ *   wrapped / clamped as trl_gather_rows does.  Everything else as trl_dqn_learn_fused_u8; same results bit for bit as
+ *   trl_gather_rows + trl_dqn_learn_fused_u8 on the same indices.
+ * `ws`: trl_dqn_learn_u8_ring_workspace_bytes() bytes. */
+int64_t trl_dqn_learn_u8_ring_workspace_bytes(const trl_mlp_desc *q_net, int64_t B);
+int trl_dqn_learn_fused_u8_ring(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const void *ring,
+                                int64_t capacity, int64_t stride, const trl_ring_layout *layout, int64_t head,
+                                int64_t count, const int64_t *idx, int64_t B, double gamma, int32_t double_dqn,
+                                int32_t kind, double huber_delta, float *loss_out, const trl_adam_args *opt, void *ws,
+                                void *stream);
 
 /* ------------------------------------------------------------------ env-step side: rollout push, exploration ("next" rows f2-f4)
  * trl_rollout_push: one env step's transitions -> the on-policy rollout columns, ONE launch.  Replaces the per-env

@@ -149,3 +149,65 @@ def test_dqn_uint8_chain_matches_oracle(K, A, hidden, B, double_dqn):
   for (name, p), q in zip(ctl.q_net.named_parameters(), ref_q.parameters()):
     # Adam's first steps move every weight by ~lr whatever the gradient's size: compare on that scale
     np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), rtol=0, atol=2e-4, err_msg=name)
+
+
+@pytest.mark.parametrize('K,A,B,cap,pushes', [(28224, 6, 64, 300, (200, 180)),      # Atari-shaped records, ring wrapped
+                                              (1024, 4, 32, 100, (60,)),            # filling ring (frames >= 1 KiB: 16 B-aligned columns)
+                                              (2048, 3, 96, 128, (128, 50))])
+def test_dqn_learn_indexed_reads_the_ring_in_place(K, A, B, cap, pushes):
+  """DQNController.learn_indexed(buffer, idx) -- the first layer and its weight gradient fetch the sampled uint8 frames
+  where the replay ring holds them (trl_dqn_learn_fused_u8_ring) -- against `learn(*buffer[idx])` (gather, then the dense
+  uint8 step) on the same indices: three consecutive steps, losses, weights and moments bit for bit; host indices drawn
+  as examples/dqn.py:40 draws them (torch's generator ends in the same state) and device indices."""
+  from torchrl_amd.utils.storage import TensorTupleDataset
+  dts = [torch.uint8, torch.float32, torch.float32, torch.uint8, torch.float32]
+  g = torch.Generator(device=DEV).manual_seed(K + B)
+
+  def fill(ds):
+    gg = torch.Generator(device=DEV).manual_seed(cap)
+    for k in pushes:
+      ds.extend(torch.randint(0, 256, (k, K), device=DEV, dtype=torch.uint8, generator=gg),
+                torch.randint(0, A, (k, 1), device=DEV, generator=gg).float(),
+                torch.randn(k, 1, device=DEV, generator=gg),
+                torch.randint(0, 256, (k, K), device=DEV, dtype=torch.uint8, generator=gg),
+                (torch.rand(k, 1, device=DEV, generator=gg) < 0.1).float())
+  ds = TensorTupleDataset(size=cap, device=DEV, storage_dtypes=dts, gather_dtypes=dts)
+  fill(ds)
+  n = len(ds)
+  assert n == min(cap, sum(pushes))
+  ctls = []
+  for _ in range(2):
+    torch.manual_seed(3)
+    c = DQNController(K, A, double_dqn=True, lr=1e-3, n_update_interval=2, device=DEV, hidden=128)
+    with torch.no_grad():
+      for net in (c.q_net, c.target_q_net):
+        net.net[0].weight.mul_(1.0 / 64)
+    c._target.data.add_(1e-3)
+    ctls.append(c)
+  a, b = ctls
+  assert torch.equal(a._q.data, b._q.data)
+  for step in range(3):
+    if step < 2:
+      torch.manual_seed(100 + step)
+      idx = ds.sample_indices(B)
+      state = torch.get_rng_state()
+      torch.manual_seed(100 + step)
+      assert torch.equal(idx, torch.randperm(n)[:B]) and torch.equal(state, torch.get_rng_state())
+    else:
+      idx = torch.randint(0, n, (B,), device=DEV, generator=g)      # device-resident indices
+    view = ds.ring_view(idx)
+    assert a._fused.ring_usable(view)
+    view['done']()
+    la = a.learn_indexed(ds, idx, in_place=True)['td_loss']
+    lb = b.learn(*ds[idx])['td_loss']
+    torch.cuda.synchronize()
+    assert float(la) == float(lb), (step, float(la), float(lb))
+  assert torch.equal(a._q.data, b._q.data) and torch.equal(a._target.data, b._target.data)
+  assert torch.equal(a.q_net_optim.exp_avg, b.q_net_optim.exp_avg) and torch.equal(a.q_net_optim.exp_avg_sq, b.q_net_optim.exp_avg_sq)
+  assert torch.equal(a._q.grad, b._q.grad)
+  # a buffer the in-place step does not take (float32 frames) goes through learn(*buffer[idx])
+  dsf = TensorTupleDataset(size=64, device=DEV)
+  dsf.extend(torch.randn(64, 8, device=DEV), torch.randint(0, 2, (64, 1), device=DEV).float(), torch.randn(64, 1, device=DEV),
+             torch.randn(64, 8, device=DEV), torch.zeros(64, 1, device=DEV))
+  cf = DQNController(8, 2, device=DEV)
+  assert torch.isfinite(cf.learn_indexed(dsf, torch.arange(32), in_place=True)['td_loss']).item()

@@ -127,6 +127,9 @@ PROTOTYPES = {
     'trl_dqn_learn_fused': (C.c_int, [C.POINTER(MlpDesc)] * 2 + [_vp] * 5 + [_i64, _f64, _i32, _i32, _f64, _vp,
                                       C.POINTER(AdamArgs), _vp, _vp]),
     'trl_dqn_learn_u8_workspace_bytes': (_i64, [C.POINTER(MlpDesc), _i64]),
+    'trl_dqn_learn_u8_ring_workspace_bytes': (_i64, [C.POINTER(MlpDesc), _i64]),
+    'trl_dqn_learn_fused_u8_ring': (C.c_int, [C.POINTER(MlpDesc)] * 2 + [_vp, _i64, _i64, C.POINTER(RingLayout), _i64, _i64, _vp,
+                                              _i64, _f64, _i32, _i32, _f64, _vp, C.POINTER(AdamArgs), _vp, _vp]),
     'trl_dqn_learn_fused_u8': (C.c_int, [C.POINTER(MlpDesc)] * 2 + [_vp] * 5 + [_i64, _f64, _i32, _i32, _f64, _vp,
                                       C.POINTER(AdamArgs), _vp, _vp]),
 }

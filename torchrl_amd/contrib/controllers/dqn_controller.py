@@ -109,6 +109,28 @@ class DQNController(Controller):
       self.q_net_optim.step()
     return loss.detach()
 
+  def learn_indexed(self, buffer, indices, in_place=False):
+    """`self.learn(*[b.to(device) for b in buffer[indices]])` (examples/dqn.py:40-42) from the buffer and the sampled row
+    numbers.  in_place=True: where the buffer is a ring of Transitions with uint8 frames and the Q-network is on the fused
+    uint8 path, no batch is gathered -- the first layer and its weight gradient read the sampled frames where the ring
+    holds them (trl_dqn_learn_fused_u8_ring: the gather as the layer's operand fetch).  Same result, bit for bit.
+    It is NOT the default because it measured slower (0.127 against 0.120 ms per step, B = 256, 4 M-record ring): the
+    step reads every sampled frame two to three times (obs: forward + weight gradient; next_obs: target and online
+    pass), the dense 14 MB batch turns those re-reads into L2 / Infinity-Cache hits, and the 9 us copy that makes it is
+    cheaper than re-reading scattered 28 KB records of a 226 GB ring.  indices: int64 tensor of
+    logical rows (host: validated like torch indexing; device: not), e.g. buffer.sample_indices(batch_size)."""
+    need_hip(self.device, 'DQNController.learn_indexed')
+    f = self._fused
+    if in_place and f is not None and not self._sync.enabled and self._run.graphed is None and hasattr(buffer, 'ring_view'):
+      view = buffer.ring_view(indices)
+      if f.ring_usable(view):
+        self.q_net.train()
+        loss = f.from_ring(view, self.gamma, self.q_net_optim, double_dqn=self.double_dqn, update=True,
+                           huber_delta=self.huber_delta)[0]
+        return self._after_step(loss)
+      view['done']()
+    return self.learn(*buffer[indices])
+
   def learn(self, obs, action, reward, next_obs, done):
     need_hip(self.device, 'DQNController.learn')
     self.q_net.train()
@@ -116,6 +138,11 @@ class DQNController(Controller):
     if self._sync.enabled:
       self._sync.all_reduce(self._q)
       self.q_net_optim.step()
+    return self._after_step(loss)
+
+  def _after_step(self, loss):
+    """What follows the optimizer step in DQNController.learn (dqn_controller.py:84-88): the step count, the periodic hard
+    target sync, the loss dict."""
     self.q_net_optim.note_step()
 
     self._steps += 1

@@ -142,10 +142,20 @@ struct TrlU8Update {
   TrlAdamScalars s;
 };
 int64_t trl_u8_fwd_ws_floats(int64_t B, int32_t N, int32_t K, int P);
+// rec != NULL: the uint8 rows are read in place out of a replay ring -- row b of x starts at x + rec[b] * stride bytes
+// (x = ring base + the frame column's offset in a record, rec[b] = the physical record of batch row b)
 int trl_u8_fwd_launch(const char *fn, int P, const uint8_t *const *x, const float *const *w, const float *const *b,
-                      float *const *y, int64_t B, int32_t K, int32_t N, int32_t act, float *ws, hipStream_t st);
+                      float *const *y, int64_t B, int32_t K, int32_t N, int32_t act, float *ws, hipStream_t st,
+                      const int32_t *rec, int64_t stride);
 int trl_u8_wgrad_launch(const char *fn, const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
-                        float *db, const TrlU8Update *u, hipStream_t st);
+                        float *db, const TrlU8Update *u, hipStream_t st, const int32_t *rec, int64_t stride);
+
+// ---- csrc/trl_replay.hip: the prologue of a learner step that reads its frames in place (csrc/trl_offpolicy.hip).  One
+// launch: rec[b] = the physical record of logical row idx[b] (idx: device or pinned host memory), and the three
+// one-float columns of a transition (action, reward, done) gathered densely
+int trl_ring_rows_launch(const char *fn, const void *ring, int64_t capacity, int64_t stride, int64_t head, int64_t count,
+                         const int64_t *idx, int64_t B, const int32_t *f32_col_off /*[3]*/, int32_t *rec, float *action,
+                         float *reward, float *done, hipStream_t st);
 
 // ---- device-resident Adam state (csrc/trl_loss.hip), for chains that are captured into a HIP graph
 int trl_adam_prep_launch(const char *fn, trl_adam_state *state, hipStream_t st);     // ++step, derive the scalars

@@ -76,6 +76,10 @@ constexpr int MAX_PROBLEMS = 3;   // the three first-layer passes of a Double-DQ
 
 struct FwdArgs {
   const uint8_t *x[MAX_PROBLEMS];
+  // rows read in place out of a replay ring: row b of problem p starts at x[p] + rec[b] * stride bytes (x[p] = the
+  // ring's base plus the frame column's offset in a record, rec[b] = the physical record); NULL = dense [B, K] operands
+  const int32_t *rec;
+  int64_t stride;
   const float *w[MAX_PROBLEMS];
   float *ws;       // [P][S][Bpad][N] partial tiles
   int B, N, K, Bpad, bps, kblocks, S;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void k_lin_u8_fwd(FwdArgs a) {
   for (int i = 0; i < WI; ++i) {
     int row = r0 + 32 * i + lr;
     row = row < a.B ? row : a.B - 1;            // padding rows read a valid row; their results are never used
-    xr[i] = xbase + (size_t)row * a.K + 16 * kh;
+    xr[i] = xbase + (a.rec ? (size_t)a.rec[row] * (size_t)a.stride : (size_t)row * a.K) + 16 * kh;
   }
 #pragma unroll
   for (int t = 0; t < WT; ++t) wr[t] = wbase + (size_t)(n0 + 32 * t + lr) * a.K + 16 * kh;   // N % 128 == 0: always valid
@@ -246,6 +250,8 @@ __global__ __launch_bounds__(256) void k_lin_u8_reduce(ReduceArgs a) {
 struct WgradArgs {
   const float *g;
   const uint8_t *x;
+  const int32_t *rec;        // as FwdArgs::rec (x = ring base + column offset, row b at x + rec[b] * stride), or NULL
+  int64_t stride;
   float *dw;       // [N, K] gradient (always written)
   float *db;       // [N] column sums of g, or NULL
   // update != 0: torch.optim.Adam's step on the weight (and bias) right where its gradient is produced
@@ -283,7 +289,12 @@ __global__ __launch_bounds__(256) void k_lin_u8_wgrad(WgradArgs a) {
     }
     return;
   }
-  const uint8_t *xp = a.x + (size_t)(16 * h) * a.K + kc;
+  // row r of x: dense at r * K, or the ring record rec[r].  The record numbers of a block's 16 rows are fetched a block
+  // before the x loads that need them (the loads of block bb + 1 are issued under the MFMAs of block bb).
+  const bool ring = a.rec != nullptr;
+  auto xrow = [&](int r, int recno) -> const uint8_t * {
+    return a.x + (ring ? (size_t)recno * (size_t)a.stride : (size_t)r * a.K) + kc;
+  };
   f16v acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -291,20 +302,27 @@ __global__ __launch_bounds__(256) void k_lin_u8_wgrad(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float ga[16], gn[16];
   unsigned int xa[16], xn[16];
+  int rn[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
+    const int r = 16 * h + j;
     ga[j] = gp[(size_t)j * a.N];
-    xa[j] = *(const unsigned int *)(xp + (size_t)j * a.K);
+    xa[j] = *(const unsigned int *)xrow(r, ring ? a.rec[r] : 0);
+    rn[j] = (ring && nblk > 1) ? a.rec[32 + r] : 0;
   }
   for (int bb = 0; bb < nblk; ++bb) {
     const bool more = bb + 1 < nblk;
     if (more) {
       const float *g2 = gp + (size_t)(bb + 1) * 32 * a.N;
-      const uint8_t *x2 = xp + (size_t)(bb + 1) * 32 * a.K;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
+        const int r = (bb + 1) * 32 + 16 * h + j;
         gn[j] = g2[(size_t)j * a.N];
-        xn[j] = *(const unsigned int *)(x2 + (size_t)j * a.K);
+        xn[j] = *(const unsigned int *)xrow(r, rn[j]);
+      }
+      if (ring && bb + 2 < nblk) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rn[j] = a.rec[(bb + 2) * 32 + 16 * h + j];
       }
     }
     // A lane's 16 batch rows are two MFMA k groups of 8 (slot (lane half, jj) <-> row 16 h + 8 m + jj on both operands);
@@ -385,7 +403,8 @@ int64_t trl_u8_fwd_ws_floats(int64_t B, int32_t N, int32_t K, int P) {
 }
 
 int trl_u8_fwd_launch(const char *fn, int P, const uint8_t *const *x, const float *const *w, const float *const *b,
-                      float *const *y, int64_t B, int32_t K, int32_t N, int32_t act, float *ws, hipStream_t st) {
+                      float *const *y, int64_t B, int32_t K, int32_t N, int32_t act, float *ws, hipStream_t st,
+                      const int32_t *rec, int64_t stride) {
   FwdPlan p;
   TRL_REQUIRE(fwd_plan(B, N, K, P, &p), "%s: uint8 first layer needs B in [1, 2^20], N %% 128 == 0, K %% 32 == 0 "
               "(B=%lld N=%d K=%d)", fn, (long long)B, N, K);
@@ -400,7 +419,9 @@ int trl_u8_fwd_launch(const char *fn, int P, const uint8_t *const *x, const floa
     r.bias[i] = b[j]; r.y[i] = y[j];
   }
   TRL_REQUIRE(ws && (uintptr_t)ws % 16 == 0, "%s: workspace must be 16 B aligned", fn);
+  TRL_REQUIRE(!rec || stride % 16 == 0, "%s: ring records must be a multiple of 16 B apart", fn);
   a.ws = ws;
+  a.rec = rec; a.stride = stride;
   a.B = (int)B; a.N = N; a.K = K; a.Bpad = p.Bpad; a.bps = p.bps; a.kblocks = p.kblocks; a.S = p.S;
   hipLaunchKernelGGL(k_lin_u8_fwd, dim3(p.S, p.mtiles * (N / FWD_NT), P), dim3(256), 0, st, a);
   TRL_CHECK_LAUNCH(fn);
@@ -411,7 +432,7 @@ int trl_u8_fwd_launch(const char *fn, int P, const uint8_t *const *x, const floa
 }
 
 int trl_u8_wgrad_launch(const char *fn, const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
-                        float *db, const TrlU8Update *u, hipStream_t st) {
+                        float *db, const TrlU8Update *u, hipStream_t st, const int32_t *rec, int64_t stride) {
   TRL_REQUIRE(g && x && dw, "%s: null pointer", fn);
   TRL_REQUIRE(B >= 32 && B % 32 == 0 && B <= (1 << 20) && N > 0 && N % 128 == 0 && K >= 4 && K % 4 == 0,
               "%s: uint8 weight gradient needs B %% 32 == 0, N %% 128 == 0, K %% 4 == 0 (B=%lld N=%d K=%d)", fn,
@@ -421,6 +442,8 @@ int trl_u8_wgrad_launch(const char *fn, const float *g, const uint8_t *x, int64_
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.g = g; a.x = x; a.dw = dw; a.db = db; a.B = (int)B; a.N = N; a.K = K;
+  TRL_REQUIRE(!rec || stride % 4 == 0, "%s: ring records must be a multiple of 4 B apart", fn);
+  a.rec = rec; a.stride = stride;
   if (u) {
     TRL_REQUIRE(db && u->pw && u->mw && u->vw && u->pb && u->mb && u->vb, "%s: the in-launch update needs every buffer", fn);
     a.update = 1;
@@ -440,10 +463,10 @@ extern "C" int trl_linear_u8_fwd(const uint8_t *x, const float *w, const float *
   const char *fn = "trl_linear_u8_fwd";
   TRL_REQUIRE(x && w && b && y && ws, "%s: null pointer", fn);
   TRL_REQUIRE(act == 0 || act == 1, "%s: act must be 0 (none) or 1 (relu)", fn);
-  return trl_u8_fwd_launch(fn, 1, &x, &w, &b, &y, B, K, N, act, (float *)ws, (hipStream_t)stream);
+  return trl_u8_fwd_launch(fn, 1, &x, &w, &b, &y, B, K, N, act, (float *)ws, (hipStream_t)stream, nullptr, 0);
 }
 
 extern "C" int trl_linear_u8_wgrad(const float *g, const uint8_t *x, int64_t B, int32_t K, int32_t N, float *dw,
                                    void *stream) {
-  return trl_u8_wgrad_launch("trl_linear_u8_wgrad", g, x, B, K, N, dw, nullptr, nullptr, (hipStream_t)stream);
+  return trl_u8_wgrad_launch("trl_linear_u8_wgrad", g, x, B, K, N, dw, nullptr, nullptr, (hipStream_t)stream, nullptr, 0);
 }

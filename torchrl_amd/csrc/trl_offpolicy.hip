@@ -1088,10 +1088,12 @@ int64_t dqn_ws_floats(const trl_mlp_desc *q_net, int64_t B, bool u8, int npass) 
 // obs / next_obs are float32 [B, S], or (u8) uint8 [B, S]: then layer 0 runs on csrc/trl_linear_u8.hip --
 // all passes in one split-K launch + one reduce launch, its weight gradient in one launch, its Adam step
 // as a streaming launch -- and the rest of the chain is unchanged (9 launches in all).
+// rec != NULL (u8 only): obs / next_obs are the ring's base plus the frame columns' offsets and batch row b is record
+// rec[b], `stride` bytes apart -- the first layer reads the frames where the replay ring holds them
 int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const void *obs,
                    const float *action, const float *reward, const void *next_obs, const float *done, int64_t B64,
                    double gamma, int32_t double_dqn, int32_t kind, double huber_delta, float *loss_out,
-                   const trl_adam_args *opt, void *ws, void *stream) {
+                   const trl_adam_args *opt, void *ws, void *stream, const int32_t *rec = nullptr, int64_t rstride = 0) {
   TRL_REQUIRE(opt != nullptr, "%s: the optimizer block is required (step == 0: gradients only)", fn);
   int rc;
   if ((rc = check_net(fn, "q_net", q_net, opt, u8)) || (rc = check_net(fn, "target_net", target_net, nullptr, u8)))
@@ -1125,7 +1127,7 @@ int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl
       for (int j = 0; j < npass; ++j) {
         x8[j] = (const uint8_t *)xs[j]; w8[j] = nets[j]->w[0]; b8[j] = nets[j]->b[0]; y8[j] = W.h0[j];
       }
-      if ((rc = trl_u8_fwd_launch(fn, npass, x8, w8, b8, y8, B, S, H0, ACT_RELU, u8_ws, st))) return rc;
+      if ((rc = trl_u8_fwd_launch(fn, npass, x8, w8, b8, y8, B, S, H0, ACT_RELU, u8_ws, st, rec, rstride))) return rc;
       continue;
     }
     Phase ph;
@@ -1151,7 +1153,8 @@ int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl
     // after the MFMA work of ALL of them instead of beside it (measured 61 us against 25 + 15 us apart):
     // the 3.6 M-parameter update is its own streaming launch over the layer's slice of the flat buffers.
     const int64_t wo = off(q_net->w[0]), bo = off(q_net->b[0]);
-    if ((rc = trl_u8_wgrad_launch(fn, W.g0, (const uint8_t *)obs, B, S, H0, opt->grad + wo, opt->grad + bo, nullptr, st)))
+    if ((rc = trl_u8_wgrad_launch(fn, W.g0, (const uint8_t *)obs, B, S, H0, opt->grad + wo, opt->grad + bo, nullptr, st, rec,
+                                  rstride)))
       return rc;
     if (U.mode >= UPD_ADAM) {
       const int64_t nw = (int64_t)H0 * S;
@@ -1206,4 +1209,49 @@ extern "C" int trl_dqn_learn_fused_u8(const trl_mlp_desc *q_net, const trl_mlp_d
                                       void *stream) {
   return dqn_learn_impl("trl_dqn_learn_fused_u8", true, q_net, target_net, obs, action, reward, next_obs, done, B64,
                         gamma, double_dqn, kind, huber_delta, loss_out, opt, ws, stream);
+}
+
+// ---- the same step with the frames read in place: the gather of examples/dqn.py:40-41 becomes the first layer's operand
+// fetch (no [B, 28224] uint8 copies of obs and next_obs), a small prologue launch resolves the sampled rows' records and
+// gathers the 12 B action / reward / done tail.  Workspace = the u8 step's + B x (4 + 12) bytes.
+namespace {
+int64_t ring_tail_floats(int64_t B) { return (4 * B + 63) / 64 * 64; }      // rec (as int32), action, reward, done
+}  // namespace
+
+extern "C" int64_t trl_dqn_learn_u8_ring_workspace_bytes(const trl_mlp_desc *q_net, int64_t B) {
+  if (!q_net || B <= 0 || q_net->depth != 3) return 0;
+  return (dqn_ws_floats(q_net, B, true, 3) + ring_tail_floats(B)) * (int64_t)sizeof(float);
+}
+
+extern "C" int trl_dqn_learn_fused_u8_ring(const trl_mlp_desc *q_net, const trl_mlp_desc *target_net, const void *ring,
+                                           int64_t capacity, int64_t stride, const trl_ring_layout *layout, int64_t head,
+                                           int64_t count, const int64_t *idx, int64_t B64, double gamma, int32_t double_dqn,
+                                           int32_t kind, double huber_delta, float *loss_out, const trl_adam_args *opt,
+                                           void *ws, void *stream) {
+  const char *fn = "trl_dqn_learn_fused_u8_ring";
+  TRL_REQUIRE(q_net && target_net && ring && layout && idx && loss_out && opt && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(q_net->depth == 3, "%s: q_net must have two hidden layers", fn);
+  // the record must be a Transition (torchrl/utils/storage.py:51-57): obs, action, reward, next_obs, done, with uint8
+  // frames of the first layer's fan-in and one float32 each for the other three
+  TRL_REQUIRE(layout->ncols == 5, "%s: the ring must hold the five columns of a Transition, got %d", fn, layout->ncols);
+  for (int c : {0, 3})
+    TRL_REQUIRE(layout->col_dtype[c] == TRL_U8 && layout->col_bytes[c] == q_net->dims[0] && layout->col_off[c] % 16 == 0,
+                "%s: column %d must be %d uint8 values at a 16 B-aligned offset", fn, c, q_net->dims[0]);
+  for (int c : {1, 2, 4})
+    TRL_REQUIRE(layout->col_dtype[c] == TRL_F32 && layout->col_bytes[c] == 4, "%s: column %d must be one float32", fn, c);
+  TRL_REQUIRE(stride % 16 == 0 && ((uintptr_t)ring & 15) == 0, "%s: ring base and record stride must be multiples of 16 B", fn);
+  TRL_REQUIRE(B64 >= 32 && B64 % 32 == 0 && B64 <= MAX_BATCH, "%s: B = %lld must be a multiple of 32 in [32, %d]", fn,
+              (long long)B64, MAX_BATCH);
+  TRL_REQUIRE(aligned16(ws), "%s: workspace must be 16 B aligned", fn);
+  float *tail = (float *)ws + dqn_ws_floats(q_net, B64, true, 3);
+  int32_t *rec = (int32_t *)tail;
+  float *action = tail + B64, *reward = tail + 2 * B64, *done = tail + 3 * B64;
+  const int32_t offs[3] = {layout->col_off[1], layout->col_off[2], layout->col_off[4]};
+  int rc;
+  if ((rc = trl_ring_rows_launch(fn, ring, capacity, stride, head, count, idx, B64, offs, rec, action, reward, done,
+                                 (hipStream_t)stream)))
+    return rc;
+  return dqn_learn_impl(fn, true, q_net, target_net, (const char *)ring + layout->col_off[0], action, reward,
+                        (const char *)ring + layout->col_off[3], done, B64, gamma, double_dqn, kind, huber_delta, loss_out,
+                        opt, ws, stream, rec, stride);
 }

@@ -299,6 +299,25 @@ __global__ __launch_bounds__(256) void k_gather_wide(
   }
 }
 
+// ---- rows in place ------------------------------------------------------------------
+// The prologue of a learner step whose first layer reads its frames straight out of the ring (trl_dqn_learn_fused_u8_ring):
+// the physical record of every sampled row, and the transition's three one-float columns gathered densely (12 B per
+// row; the two 28 KB frames of a row are NOT copied: the first layer's operand fetch reads them where they lie).
+__global__ __launch_bounds__(256) void k_ring_rows(const char *__restrict__ ring, int64_t capacity, int64_t stride,
+                                                   int64_t head, int64_t count, const int64_t *__restrict__ idx, int64_t B,
+                                                   int off_a, int off_r, int off_d, int32_t *__restrict__ rec,
+                                                   float *__restrict__ action, float *__restrict__ reward,
+                                                   float *__restrict__ done) {
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+    const int64_t p = logical_to_record(idx[b], head, count, capacity);
+    const char *r = ring + p * stride;
+    rec[b] = (int32_t)p;
+    action[b] = *(const float *)(r + off_a);
+    reward[b] = *(const float *)(r + off_r);
+    done[b] = *(const float *)(r + off_d);
+  }
+}
+
 // ---- push ---------------------------------------------------------------------------
 // src columns are dense [k, w_bytes].  Value of dword d of new row r (0 for padding).
 __device__ __forceinline__ uint32_t push_dword(const ColArgs &a, int64_t r, int d) {
@@ -520,6 +539,21 @@ extern "C" int trl_gather_range(const void *ring, int64_t capacity, int64_t stri
                                 void *stream) {
   return gather_impl("trl_gather_range", true, ring, capacity, stride, layout, head, count, nullptr, start,
                      B, dst, out_dtype, stream);
+}
+
+int trl_ring_rows_launch(const char *fn, const void *ring, int64_t capacity, int64_t stride, int64_t head, int64_t count,
+                         const int64_t *idx, int64_t B, const int32_t *f32_col_off, int32_t *rec, float *action,
+                         float *reward, float *done, hipStream_t st) {
+  TRL_REQUIRE(ring && idx && rec && action && reward && done && f32_col_off, "%s: null pointer", fn);
+  TRL_REQUIRE(capacity > 0 && capacity < (1ll << 31) && stride > 0 && stride % 4 == 0 && count > 0 && count <= capacity &&
+              head >= 0 && head < capacity && B > 0, "%s: bad ring geometry", fn);
+  for (int i = 0; i < 3; ++i)
+    TRL_REQUIRE(f32_col_off[i] >= 0 && f32_col_off[i] % 4 == 0 && f32_col_off[i] + 4 <= stride, "%s: bad column offset", fn);
+  const unsigned grid = (unsigned)(trl_cdiv(B, 256) < 64 ? trl_cdiv(B, 256) : 64);
+  hipLaunchKernelGGL(k_ring_rows, dim3(grid), dim3(256), 0, st, (const char *)ring, capacity, stride, head, count, idx, B,
+                     f32_col_off[0], f32_col_off[1], f32_col_off[2], rec, action, reward, done);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
 }
 
 extern "C" int trl_ring_push(void *ring, int64_t capacity, int64_t stride, const trl_ring_layout *layout,

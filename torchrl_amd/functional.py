@@ -1099,3 +1099,37 @@ class FusedDqnLearn(_FusedOffPolicy):
           done.data_ptr(), B, float(gamma), 1 if double_dqn else 0, kind, delta, loss.data_ptr(), C.byref(args),
           ws.data_ptr(), _lib.stream_ptr(dev)))
     return loss
+
+  def ring_usable(self, view):
+    """A ring of Transitions with uint8 frames of this network's fan-in (the layout trl_dqn_learn_fused_u8_ring takes)."""
+    lay = view['layout']
+    B = view['idx'].numel()
+    return (self.u8_ok and lay.ncols == 5 and lay.storage_dtypes[0] == torch.uint8 and lay.storage_dtypes[3] == torch.uint8
+            and lay.col_bytes[0] == self.S and lay.col_bytes[3] == self.S and lay.col_bytes[1] == lay.col_bytes[2] ==
+            lay.col_bytes[4] == 4 and all(d == torch.float32 for d in (lay.storage_dtypes[1], lay.storage_dtypes[2],
+                                                                        lay.storage_dtypes[4]))
+            and lay.stride % 16 == 0 and lay.offsets[0] % 16 == 0 and lay.offsets[3] % 16 == 0
+            and B >= 32 and B % 32 == 0 and B <= self.MAX_BATCH and view['capacity'] < 2 ** 31)
+
+  def from_ring(self, view, gamma, optim, double_dqn=False, update=True, huber_delta=None):
+    """The step on rows read in place out of a replay ring (view: TensorTupleDataset.ring_view): no gathered batch,
+    the first layer fetches the sampled frames where they lie (trl_dqn_learn_fused_u8_ring).  Returns the [1] td loss."""
+    C = self._C
+    if self._ptr_key() != self._key:
+      raise _lib.TrlError('FusedDqnLearn: parameters were re-homed after construction')
+    idx = view['idx']
+    B = idx.numel()
+    dev = view['ring'].device
+    lib = _lib.lib()
+    d = self.descs
+    ws = self._ws.get(dev, lib.trl_dqn_learn_u8_ring_workspace_bytes(C.byref(d[0]), B))
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    args = optim.fused_args(update, True)
+    kind, delta = (0, 0.0) if huber_delta is None else (1, float(huber_delta))
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_dqn_learn_fused_u8_ring(
+          C.byref(d[0]), C.byref(d[1]), view['ring'].data_ptr(), view['capacity'], view['stride'], C.byref(view['layout'].c),
+          view['head'], view['count'], idx.data_ptr(), B, float(gamma), 1 if double_dqn else 0, kind, delta, loss.data_ptr(),
+          C.byref(args), ws.data_ptr(), _lib.stream_ptr(dev)))
+    view['done']()
+    return loss

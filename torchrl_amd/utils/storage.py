@@ -359,9 +359,12 @@ class TensorTupleDataset(Dataset):
   # microseconds in the middle of a step that is otherwise ~100 us of kernels.
   ZERO_COPY_MAX_ROWS = 8192
 
-  def _gather_host_index(self, index):
-    """Gather the rows listed by a HOST int64 tensor.  The indices go through a small ring of
-    pinned staging buffers; a slot is reused only after the gather that read it has finished."""
+  def _stage_host_index(self, index, zero_copy):
+    """A HOST int64 index tensor -> something a kernel can read: a slot of a small ring of pinned staging buffers
+    (reused only after the launch that read it has finished).  zero_copy: hand the pinned slot itself to the kernel
+    (mapped into the device's address space: one coalesced read over PCIe); else a copy kernel reads it into device
+    memory first (trl_stage_indices: still no DMA-engine copy in the stream).  Returns (idx, event): record the event
+    behind the consuming launch."""
     n = index.numel()
     if self._pin is None or self._pin[0][0].numel() < n:
       if self._pin is not None:
@@ -378,20 +381,51 @@ class TensorTupleDataset(Dataset):
     self._pin_next = (slot + 1) % len(self._pin)
     buf, ev = self._pin[slot]
     if self._pin_used[slot]:
-      ev.synchronize()            # the gather issued 4 calls ago has long finished
+      ev.synchronize()            # the launch issued 4 calls ago has long finished
     buf[:n].copy_(index)
-    # (narrow records only: there one wave per 64 rows reads the indices once; the wide kernel reads a
+    self._pin_used[slot] = True
+    if zero_copy and n <= self.ZERO_COPY_MAX_ROWS and os.environ.get('TRL_INDEX_ZERO_COPY', '1') != '0':
+      return buf[:n], ev          # pinned host memory is mapped into the device's address space
+    idx = torch.empty(n, dtype=torch.int64, device=self._device)
+    with torch.cuda.device(self._device):
+      _lib.check(_lib.lib().trl_stage_indices(buf.data_ptr(), idx.data_ptr(), n, _lib.stream_ptr(self._device)))
+    return idx, ev
+
+  def _gather_host_index(self, index):
+    """Gather the rows listed by a HOST int64 tensor."""
+    # (zero-copy for narrow records only: there one wave per 64 rows reads the indices once; the wide kernel reads a
     # row's index in every workgroup that copies one of its chunks, which must come from HBM / L2)
-    if n <= self.ZERO_COPY_MAX_ROWS and not self._layout.has_wide and os.environ.get('TRL_INDEX_ZERO_COPY', '1') != '0':
-      idx = buf[:n]               # pinned host memory is mapped into the device's address space
-    else:             # a copy kernel reading the pinned buffer, not a DMA-engine copy (trl_stage_indices)
-      idx = torch.empty(n, dtype=torch.int64, device=self._device)
-      with torch.cuda.device(self._device):
-        _lib.check(_lib.lib().trl_stage_indices(buf.data_ptr(), idx.data_ptr(), n, _lib.stream_ptr(self._device)))
+    idx, ev = self._stage_host_index(index, zero_copy=not self._layout.has_wide)
     outs = self._gather_index(idx)
     ev.record(torch.cuda.current_stream(self._device))
-    self._pin_used[slot] = True
     return outs
+
+  # ------------------------------------------------------------------ rows in place (no gather)
+  def sample_indices(self, batch_size, generator=None):
+    """The index draw of sample() alone: `torch.randperm(len(self), generator=generator)[:batch_size]` (examples/dqn.py:40)
+    bit for bit, as a host int64 tensor -- for a learner that reads the sampled rows in place
+    (DQNController.learn_indexed) instead of gathering them first."""
+    ahead = self._count if (generator is None and self._count == self._capacity) else None
+    return randperm_prefix(self._count, batch_size, generator, next_n=ahead)
+
+  def ring_view(self, index):
+    """What a kernel needs to read the rows `index` (int64 tensor, host or device, logical row numbers as
+    `self[index]` takes them) where they lie: dict(ring, capacity, stride, layout, head, count, idx, done) --
+    idx a tensor the device can read; call done() right after enqueueing the consumer."""
+    if self._layout is None or self._count == 0:
+      raise TypeError("'NoneType' object is not iterable")
+    if not torch.is_tensor(index) or index.dtype != torch.int64 or index.dim() != 1:
+      raise TypeError('ring_view takes a 1-D int64 tensor of row numbers')
+    n = self._count
+    if index.is_cuda:
+      idx, done = index.to(self._device).contiguous(), (lambda: None)
+    else:
+      if index.numel() and (int(index.min()) < -n or int(index.max()) >= n):
+        raise IndexError('index out of range for %d rows' % n)
+      idx, ev = self._stage_host_index(index.contiguous(), zero_copy=True)
+      done = lambda: ev.record(torch.cuda.current_stream(self._device))
+    return dict(ring=self._ring, capacity=self._capacity, stride=self._layout.stride, layout=self._layout, head=self._head,
+                count=self._count, idx=idx, done=done)
 
   def __getitems__(self, indices):
     """torch's batched-fetch hook (torch.utils.data's fetcher calls it with a minibatch's list of row
@@ -473,6 +507,22 @@ class TensorTupleDataset(Dataset):
                                                idx.data_ptr(), _lib.stream_ptr(self._device)))
     self.last_indices = idx
     return self._gather_index(idx)
+
+  def sample_indices_device(self, batch_size, seed=None):
+    """The index draw of sample_device() alone (trl_sample_indices: distinct, uniform, Philox on the device -- throughput
+    mode, not torch.randperm's indices): an int64 device tensor for DQNController.learn_indexed."""
+    if self._layout is None or self._count == 0:
+      raise TypeError("'NoneType' object is not iterable")
+    B = int(batch_size)
+    if getattr(self, '_dev_rng', None) is None:
+      self._dev_seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)
+      self._dev_rng = torch.zeros(1, dtype=torch.int64, device=self._device)     # the call counter
+    idx = torch.empty(B, dtype=torch.int64, device=self._device)
+    with torch.cuda.device(self._device):
+      _lib.check(_lib.lib().trl_sample_indices(self._count, B, C.c_uint64(self._dev_seed), self._dev_rng.data_ptr(),
+                                               idx.data_ptr(), _lib.stream_ptr(self._device)))
+    self.last_indices = idx
+    return idx
 
   def iter_batches(self, batch_size):
     """Sequential minibatches, last partial batch kept: the order of
