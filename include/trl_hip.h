@@ -415,6 +415,21 @@ int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         int64_t n_rows, int64_t minibatch, int32_t n_epochs, int32_t A, double clip, double alpha,
                         double beta, float *losses_out, const trl_adam_args *adam, void *ws, void *stream);
 
+/* ONE PPOController.learn step (ppo_controller.py:53-80) over a batch of any size through the tile pipeline of
+ * trl_ppo_learn_epoch, spread over the chip: 128 slabs of the batch x two workgroups (critic, actor), each leaving its
+ * partial gradient sums, then one reduce launch that adds the slabs in order, writes every gradient to its place in
+ * adam->grad and (update != 0) applies clip_grad_value_ + Adam as trl_adam_step does.  The general whole-step path:
+ * it takes every shape trl_ppo_learn_epoch takes (fan-in <= 15, 1..4 actions, one hidden layer up to 256 wide or two up
+ * to 64) -- in particular the ones trl_ppo_learn_fused's register-chained kernels do not (more than two actions, a
+ * 256-wide layer over 10..15 observations) and that would otherwise run layer by layer.  Arguments as
+ * trl_ppo_learn_fused; losses_out[0..3]; adam->step = the 1-based count of this update when update != 0.
+ * `ws`: trl_ppo_learn_tiles_workspace_bytes(adam->n, B) bytes. */
+int64_t trl_ppo_learn_tiles_workspace_bytes(int64_t n_flat, int64_t B);
+int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std, const float *obs,
+                        const float *action, const float *returns, const float *old_logp, const float *adv, int64_t B,
+                        int32_t A, double clip, double alpha, double beta, float *losses_out, const trl_adam_args *adam,
+                        int32_t update, void *ws, void *stream);
+
 /* ------------------------------------------------------------------ fused off-policy learner steps (a-2 + a-4)
  * DDPGController.learn (ddpg_controller.py:101-128) as 10 phases of one tile kernel (csrc/trl_offpolicy.hip;
  * one launch, or one per phase: trl_offpolicy_set_chain): the five

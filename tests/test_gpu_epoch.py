@@ -199,3 +199,57 @@ def test_fast_adam_is_trl_adam_elem_bit_for_bit():
   r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'adam_compare_child.py')], env=env, capture_output=True,
                      text=True, timeout=110)
   assert r.returncode == 0 and 'adam compare child ok' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+# ---------------------------------------------------------------- one big batch through the tile pipeline (trl_ppo_learn_tiles)
+TILE_CASES = [(8, 4, (128,), 5000), (12, 3, (256,), 3000), (15, 1, (64, 64), 70001), (3, 4, (48, 32), 999), (10, 2, (256,), 40000),
+              (3, 1, (64, 64), 65536), (4, 2, (256,), 131), (2, 3, (16,), 64)]
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B', TILE_CASES)
+def test_learn_tiles_matches_oracle(obs_size, A, hidden, B):
+  """PPOController.learn on shapes the register-chained whole-step kernels do not take (three or four actions, a wide
+  layer over 10..15 observations) runs the tile pipeline spread over the chip (trl_ppo_learn_tiles) instead of layer by
+  layer; here against the oracle's torch-CPU learn(): tests/test_gpu_learn.py's bars (losses 1e-6, clipped gradients
+  1e-4 / 2e-5 of the largest, weights within 2.5 lr and < 2 % further than 1e-5)."""
+  ctl = _make(obs_size, A, hidden, obs_size + 10 * A + B)
+  assert ctl._epoch is not None
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  ref_opt = torch.optim.Adam(ref.parameters(), lr=LR)
+  obs, act, ret, old, adv = _data(obs_size, A, B, 7 + B, ref)
+  exp = loss_oracle.ppo_learn(ref, ref_opt, obs, act, None, None, None, ret, old, adv, clip=0.2, alpha=0.5, beta=1e-2,
+                              max_grad_norm=0.05)
+  exp_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+  cols = _cols(obs, act, ret, old, adv)
+  if ctl._fused is None:
+    got = ctl.learn(*cols)                      # the controller's own dispatch
+  else:                                         # a shape the register-chained kernel takes too: call the tile path itself
+    l4 = ctl._epoch.learn_tiles(cols[0], cols[1], cols[5], cols[6], cols[7], 0.2, 0.5, 1e-2, ctl.ac_net_optim)
+    got = dict(actor_loss=l4[0], critic_loss=l4[1], entropy_loss=l4[2])
+    tot = float(l4[3].cpu())
+    assert abs(tot - (float(l4[0]) + 0.5 * float(l4[1]) - 1e-2 * float(l4[2]))) <= 1e-6 * abs(tot) + 1e-7
+  torch.cuda.synchronize()
+  assert ctl.ac_net_optim.step_count == 1
+  for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+    e, v = float(exp[k]), float(got[k].cpu())
+    assert abs(v - e) <= 1e-6 * abs(e) + 2e-7, (k, v, e)
+  got_grad = ctl._flat.dense(grad=True).cpu()
+  scale = float(exp_grad.abs().max())
+  np.testing.assert_allclose(got_grad.numpy(), exp_grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
+  exp_w = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+  d = (ctl._flat.dense().cpu() - exp_w).abs()
+  assert float(d.max()) <= 2.5 * LR
+  assert float((d > 1e-5).float().mean()) < 0.02
+
+
+def test_learn_tiles_is_reproducible_and_gradients_only():
+  ctl = _make(8, 4, (128,), 3)
+  obs, act, ret, old, adv = _data(8, 4, 20000, 4, copy.deepcopy(ctl.ac_net).cpu())
+  c = _cols(obs, act, ret, old, adv)
+  outs = []
+  for _ in range(2):
+    l4 = ctl._epoch.learn_tiles(c[0], c[1], c[5], c[6], c[7], 0.2, 0.5, 1e-2, ctl.ac_net_optim, update=False)
+    torch.cuda.synchronize()
+    outs.append((l4.clone(), ctl._flat.grad.clone()))
+  assert ctl.ac_net_optim.step_count == 0                     # gradients only: nothing stepped
+  assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # slabs added in a fixed order

@@ -11,6 +11,8 @@ from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAd
 
 
 class PPOController(Controller):
+  TILES_MIN_BATCH = 32      # below this (a last partial minibatch) the layer-by-layer path
+
   def __init__(self, obs_size, action_size,
                gamma=0.99, lmbda=1.0, lr=1e-3,
                alpha=0.5, beta=1.0, clip_ratio=0.2,
@@ -142,6 +144,13 @@ class PPOController(Controller):
                            adam=self.ac_net_optim if in_kernel else None)
       if solo and not in_kernel:
         self.ac_net_optim.step()
+      return losses[:3]
+    if (self._epoch is not None and not self.ac_net_optim.device_state and obs.is_cuda and obs.dim() == 2
+        and obs.shape[0] >= self.TILES_MIN_BATCH):
+      # shapes outside the register-chained kernels (e.g. three or four actions, a 256-wide layer over 10..15 observations):
+      # the tile pipeline spread over the chip instead of the layer-by-layer path
+      losses = self._epoch.learn_tiles(obs, action, returns, old_log_probs, advantages, self.clip_ratio, self.alpha,
+                                       self.beta, self.ac_net_optim, update=not self._sync.enabled)
       return losses[:3]
     value, mean, log_std = self.ac_net.heads(obs)
     loss, parts = F.ppo_loss(mean, log_std, value, action, old_log_probs, advantages, returns,

@@ -64,6 +64,11 @@ struct Args {
   float w1, beta2, c2, eps;  // Adam's step-independent scalars
   const float *steps;        // [K][4]: bc2_sqrt, neg_step, RN(1 / bc2_sqrt), - of update k (k_epoch_prep)
   float *losses;             // [K][4]
+  // one big batch spread over many workgroups (k_ppo_tiles): workgroup (role, g) takes rows [g * slab, (g + 1) * slab) and
+  // writes its partial gradient sums to gpart + g * n_flat (indexed like the flat buffers) and loss terms to lpart
+  int64_t slab;
+  float *gpart, *lpart;      // lpart: [2][G][4]
+  int64_t n_flat;
 };
 
 // LDS map of one workgroup (offsets in floats).  Aliases: g2 (the [sample][feature] copy of layer 1's output gradient)
@@ -277,7 +282,7 @@ __global__ void k_epoch_totals(float *losses, int K, float alpha, float beta) {
 }
 
 // role: 0 critic, 1 actor; D3: two hidden layers; O: the network's fan-out
-template <int role, bool D3, int O>
+template <int role, bool D3, int O, bool TILES>
 __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   const Net &N = P.net[role];
   const Lay L = make_lay(N);
@@ -309,7 +314,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t g = N.w_off[1] + (int64_t)(r1[u] + 4 * q + r) * H1 + c1[u] + i;
-        p[r] = P.param[g]; m[r] = P.m[g]; v[r] = P.v[g];
+        p[r] = P.param[g]; m[r] = TILES ? 0.f : P.m[g]; v[r] = TILES ? 0.f : P.v[g];      // (tiles mode: no update here, no moments)
         w1[(r1[u] + 4 * q + r) * LS + c1[u] + i] = p[r];
       }
       m1[u] = (v4f){m[0], m[1], m[2], m[3]}; v1[u] = (v4f){v[0], v[1], v[2], v[3]};
@@ -333,7 +338,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     if (e < n0e) {
       const int64_t g = w0_global(e);
       if (g >= 0) {
-        m0[u] = P.m[g]; v0[u] = P.v[g];
+        if (!TILES) { m0[u] = P.m[g]; v0[u] = P.v[g]; }
         w0p[(e >> 4) * LDK + (e & 15)] = P.param[g];
       }
     }
@@ -351,13 +356,16 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   };
   for (int e = tid; e < L.NV; e += NT) {
     const int64_t g = vp_global(e);
-    vpp[e] = P.param[g]; vpm[e] = P.m[g]; vpv[e] = P.v[g];
+    vpp[e] = P.param[g];
+    if (!TILES) { vpm[e] = P.m[g]; vpv[e] = P.v[g]; }
   }
 
-  const int B = P.B;
-  const int64_t n_rows = P.n_rows;
-  const int mb_per_epoch = (int)((n_rows + B - 1) / B);
-  const int K = mb_per_epoch * P.n_epochs;
+  // tiles mode: this workgroup's slab of the one batch is walked like one minibatch, normalised by the whole batch
+  const int64_t base = TILES ? (int64_t)blockIdx.y * P.slab : 0;
+  const int64_t n_rows = TILES ? (P.n_rows - base < P.slab ? P.n_rows - base : P.slab) : P.n_rows;
+  const int B = TILES ? (int)n_rows : P.B;
+  const int mb_per_epoch = TILES ? 1 : (int)((n_rows + B - 1) / B);
+  const int K = TILES ? 1 : mb_per_epoch * P.n_epochs;
 
   // ---- input prefetch: a tile's observations are 64 * d0 consecutive floats (consecutive rows), one per thread.
   // Wave 0's lane s also carries sample s's loss inputs.
@@ -369,6 +377,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
 #pragma unroll
   for (int a = 0; a < O; ++a) in_act[a] = in_old[a] = 0.f;
   auto prefetch = [&](int64_t row0, int rows) {
+    row0 += base;
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
       const int e = tid + u * NT;
@@ -453,8 +462,9 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     int bm;
     { int64_t r0; int rr; tile_of(k, 0, r0, rr, bm); }
     const int ntile = (bm + S - 1) / S;
-    const float invB = 1.0f / (float)bm;
-    const v4f step_k = *(const v4f *)(P.steps + 4 * k);
+    const int64_t nb = TILES ? P.n_rows : (int64_t)bm;      // rows the means are taken over
+    const float invB = 1.0f / (float)nb;
+    const v4f step_k = TILES ? (v4f){1.f, 0.f, 1.f, 0.f} : *(const v4f *)(P.steps + 4 * k);
     float a_crit = 0.f, a_min = 0.f, a_ent = 0.f, a_dls[O], a_gb[O], dwl[O], db1 = 0.f;
 #pragma unroll
     for (int o = 0; o < O; ++o) a_dls[o] = a_gb[o] = dwl[o] = 0.f;
@@ -568,7 +578,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           a_gb[0] += g;
           gout[lane] = g;
         } else {
-          const float gmin = -(1.0f / (float)((int64_t)bm * O));
+          const float gmin = -(1.0f / (float)(nb * O));
 #pragma unroll
           for (int a = 0; a < O; ++a) {
             const float sigma = expf(vpp[L.o_ls + a]);
@@ -692,32 +702,72 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       for (int o = 0; o < O; ++o) part[(gp_sr * L.PO + o) * L.HLP + gp_n] = dwl[o];
       if (D3) part[(gp_sr * L.PO + O) * L.HLP + gp_n] = db1;
     }
+    float *lout = TILES ? P.lpart + ((size_t)role * gridDim.y + blockIdx.y) * 4 : P.losses + 4 * k;
     if (w == 0) {
       if (role == 0) {
         const float s_crit = trl_wave_sum(a_crit), gb = trl_wave_sum(a_gb[0]);
         if (lane == 0) {
-          P.losses[4 * k + 1] = s_crit * (1.0f / (float)bm);
+          lout[1] = TILES ? s_crit : s_crit * (1.0f / (float)nb);      // (tiles mode: the slab's raw sum; the reduce launch normalises)
           tailg[0] = gb;
         }
       } else {
-        const float invBA = 1.0f / (float)((int64_t)bm * O);
+        const float invBA = 1.0f / (float)(nb * O);
         const float s_min = trl_wave_sum(a_min), s_ent = trl_wave_sum(a_ent);
         if (lane == 0) {
-          P.losses[4 * k + 0] = -(s_min * invBA);
-          P.losses[4 * k + 2] = s_ent * invBA;
+          lout[0] = TILES ? s_min : -(s_min * invBA);
+          lout[2] = TILES ? s_ent : s_ent * invBA;
         }
+        // the entropy term's share of d loss / d log_std[a], d(-beta * mean(ent)) = -beta / A: once per batch
+        const float ent_share = (!TILES || blockIdx.y == 0) ? -P.beta / (float)O : 0.f;
 #pragma unroll
         for (int a = 0; a < O; ++a) {
           const float gb = trl_wave_sum(a_gb[a]), gl = trl_wave_sum(a_dls[a]);
           if (lane == 0) {
             tailg[a] = gb;
-            tailg[L.o_ls - L.o_bl + a] = gl + (-P.beta / (float)O);      // the entropy term's share: d(-beta * mean(ent)) / d log_std[a]
+            tailg[L.o_ls - L.o_bl + a] = gl + ent_share;
           }
         }
       }
     }
     __syncthreads();
     STAMP(9);
+    if (TILES) {
+      // ---- partial sums of this slab -> the workgroup's plane of the partial buffer (the reduce launch adds the planes
+      // in order and applies clip + Adam)
+      float *gp = P.gpart + (size_t)blockIdx.y * P.n_flat;
+      for (int e = tid; e < L.NV; e += NT) {
+        float g;
+        if (e < L.o_bl) {
+          const int o = e / HL, n = e - o * HL;
+          g = 0.f;
+          for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + o) * L.HLP + n];
+        } else if (D3 && e >= L.o_b1 && e < L.o_ls) {
+          const int n = e - L.o_b1;
+          g = 0.f;
+          for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + O) * L.HLP + n];
+        } else {
+          g = tailg[e - L.o_bl];
+        }
+        gp[vp_global(e)] = g;
+      }
+#pragma unroll
+      for (int u = 0; u < U0; ++u) {
+        const int e = tid + u * NT;
+        if (e < n0e) {
+          const int64_t go = w0_global(e);
+          if (go >= 0) gp[go] = gw0[(e >> 4) * LDK + (e & 15)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < T1; ++u) {
+        if (own1[u]) {
+          const float g[4] = {acc1[u].x, acc1[u].y, acc1[u].z, acc1[u].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gp[N.w_off[1] + (int64_t)(r1[u] + 4 * q + r) * H1 + c1[u] + i] = g[r];
+        }
+      }
+      return;
+    }
     // (by value, the per-step scalars made wave-uniform: the block must live in registers, not on the stack)
     auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
     const AdamV sc = {P.w1, P.beta2, P.c2, P.eps, P.clip, uni(step_k.x), uni(step_k.z), uni(step_k.y)};
@@ -818,8 +868,55 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
 template <bool D3, int AO>
 __global__ __launch_bounds__(NT) void k_ppo_epoch(const Args P) {
   extern __shared__ __align__(16) float lds[];
-  if (blockIdx.x == 0) epoch_body<0, D3, 1>(P, lds);
-  else epoch_body<1, D3, AO>(P, lds);
+  if (blockIdx.x == 0) epoch_body<0, D3, 1, false>(P, lds);
+  else epoch_body<1, D3, AO, false>(P, lds);
+}
+
+// One big batch: workgroup (role = blockIdx.x, g = blockIdx.y) carries slab g of the rows through the same tile pipeline
+// and leaves its partial gradient sums; k_tiles_reduce adds the slabs in order and applies clip_grad_value_ + Adam.
+template <bool D3, int AO>
+__global__ __launch_bounds__(NT) void k_ppo_tiles(const Args P) {
+  extern __shared__ __align__(16) float lds[];
+  if (blockIdx.x == 0) epoch_body<0, D3, 1, true>(P, lds);
+  else epoch_body<1, D3, AO, true>(P, lds);
+}
+
+struct Segs {
+  int n;
+  int64_t off[16];
+  int len[16];
+  int start[17];      // prefix sums of len
+};
+
+__global__ __launch_bounds__(256) void k_tiles_reduce(const float *__restrict__ gpart, const float *__restrict__ lpart, int G,
+                                                      int64_t n_flat, Segs sg, float *param, float *grad, float *m, float *v,
+                                                      TrlAdamScalars sc, int update, int64_t n_rows, int A,
+                                                      float *__restrict__ losses) {
+  const int total = sg.start[sg.n];
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    int si = 0;
+#pragma unroll
+    for (int j = 1; j < 16; ++j)
+      if (j < sg.n && t >= sg.start[j]) si = j;
+    const int64_t e = sg.off[si] + (t - sg.start[si]);
+    float g = 0.f;
+    for (int gi = 0; gi < G; ++gi) g += gpart[(size_t)gi * n_flat + e];      // slab order: reproducible
+    grad[e] = g;
+    if (update) trl_adam_elem(param + e, grad + e, m + e, v + e, sc);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 3) {
+    // the loss values: the slabs' raw sums added in double (128 partial sums of up to millions of terms each), then the
+    // means.  [1]: critic, from the critic's workgroups; [0] = -mean(min(surr1, surr2)) and [2] = mean(entropy), the actor's
+    const int role = threadIdx.x == 1 ? 0 : 1;
+    double a = 0.0;
+    for (int gi = 0; gi < G; ++gi) a += (double)lpart[((size_t)role * G + gi) * 4 + threadIdx.x];
+    const double cnt = threadIdx.x == 1 ? (double)n_rows : (double)n_rows * (double)A;
+    losses[threadIdx.x] = (float)((threadIdx.x == 0 ? -a : a) / cnt);
+  }
+}
+
+__global__ void k_tiles_total(float *losses, float alpha, float beta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) losses[3] = (losses[0] + alpha * losses[1]) - beta * losses[2];
 }
 
 constexpr int64_t MAX_LDS_BYTES = 160 * 1024;
@@ -862,6 +959,24 @@ EpochKernel pick_kernel(bool d3, int A) {
     case 3: return d3 ? k_ppo_epoch<true, 3> : k_ppo_epoch<false, 3>;
     default: return d3 ? k_ppo_epoch<true, 4> : k_ppo_epoch<false, 4>;
   }
+}
+
+EpochKernel pick_tiles_kernel(bool d3, int A) {
+  switch (A) {
+    case 1: return d3 ? k_ppo_tiles<true, 1> : k_ppo_tiles<false, 1>;
+    case 2: return d3 ? k_ppo_tiles<true, 2> : k_ppo_tiles<false, 2>;
+    case 3: return d3 ? k_ppo_tiles<true, 3> : k_ppo_tiles<false, 3>;
+    default: return d3 ? k_ppo_tiles<true, 4> : k_ppo_tiles<false, 4>;
+  }
+}
+
+// slabs of a batch of n rows: whole 64-row tiles, at most MAX_SLABS of them
+constexpr int MAX_SLABS = 128;
+void slab_plan(int64_t n, int64_t *slab, int *G) {
+  const int64_t tiles = (n + S - 1) / S;
+  const int64_t per = (tiles + MAX_SLABS - 1) / MAX_SLABS;
+  *slab = per * S;
+  *G = (int)((n + *slab - 1) / *slab);
 }
 
 }  // namespace
@@ -990,6 +1105,89 @@ extern "C" int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_des
   hipLaunchKernelGGL(kern, dim3(2), dim3(NT), (size_t)lds_bytes, st, P);
   TRL_CHECK_LAUNCH(fn);
   hipLaunchKernelGGL(k_epoch_totals, dim3((K + 255) / 256), dim3(256), 0, st, losses_out, K, P.alpha, P.beta);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
+}
+
+// ---- one learn() step over ONE batch of any size through the same tile pipeline, spread over the chip: the general
+// whole-step path for the shapes trl_ppo_learn_epoch takes (fan-in <= 15, up to four actions, one hidden layer up to 256
+// wide or two up to 64) -- some of which trl_ppo_learn_fused's register-chained kernels do not
+extern "C" int64_t trl_ppo_learn_tiles_workspace_bytes(int64_t n_flat, int64_t B) {
+  if (n_flat <= 0 || B <= 0) return 0;
+  int64_t slab; int G;
+  slab_plan(B, &slab, &G);
+  return ((int64_t)G * n_flat + 2 * (int64_t)G * 4 + 64) * (int64_t)sizeof(float);
+}
+
+extern "C" int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                   const float *obs, const float *action, const float *returns, const float *old_logp,
+                                   const float *adv, int64_t B, int32_t A, double clip, double alpha, double beta,
+                                   float *losses_out, const trl_adam_args *adam, int32_t update, void *ws, void *stream) {
+  const char *fn = "trl_ppo_learn_tiles";
+  TRL_REQUIRE(adam && adam->param && adam->grad && adam->n > 0, "%s: the optimizer block (flat buffers) is required", fn);
+  TRL_REQUIRE(!update || (adam->exp_avg && adam->exp_avg_sq && adam->step >= 1 && !adam->dev_state),
+              "%s: update needs the moment buffers and a host step count >= 1", fn);
+  TRL_REQUIRE(A >= 1 && A <= MAXO, "%s: action size %d must be in [1, %d]", fn, A, MAXO);
+  TRL_REQUIRE(B >= 1 && B <= (1ll << 31) - 64, "%s: bad batch size", fn);
+  TRL_REQUIRE(obs && action && returns && old_logp && adv && losses_out && log_std && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(((uintptr_t)ws & 15) == 0, "%s: the workspace must be 16 B aligned", fn);
+  Args P = {};
+  int rc;
+  if ((rc = fill_net(fn, "critic", critic, adam, 1, P.net[0])) || (rc = fill_net(fn, "actor", actor, adam, A, P.net[1])))
+    return rc;
+  TRL_REQUIRE(P.net[0].d0 == P.net[1].d0 && P.net[0].depth == P.net[1].depth,
+              "%s: critic and actor must have the same fan-in and depth", fn);
+  const int64_t lo = log_std - adam->param;
+  TRL_REQUIRE(lo >= 0 && lo + A <= adam->n, "%s: log_std must lie inside the optimizer's flat buffer", fn);
+  P.net[1].ls_off = lo;
+  int64_t lds_bytes = 0;
+  for (int r = 0; r < 2; ++r) {
+    const int64_t b = (int64_t)make_lay(P.net[r]).total * 4;
+    lds_bytes = b > lds_bytes ? b : lds_bytes;
+  }
+  TRL_REQUIRE(lds_bytes <= MAX_LDS_BYTES, "%s: networks of this size need %lld B of LDS (limit %lld)", fn,
+              (long long)lds_bytes, (long long)MAX_LDS_BYTES);
+  int G;
+  slab_plan(B, &P.slab, &G);
+  P.param = adam->param; P.grad = adam->grad; P.m = adam->exp_avg; P.v = adam->exp_avg_sq;
+  P.obs = obs; P.action = action; P.returns = returns; P.old_logp = old_logp; P.adv = adv;
+  P.n_rows = B; P.B = 0; P.n_epochs = 1; P.A = A;
+  P.lo = (float)(1.0 - clip); P.hi = (float)(1.0 + clip); P.alpha = (float)alpha; P.beta = (float)beta;
+  P.clip = __builtin_inff();
+  P.n_flat = adam->n;
+  P.gpart = (float *)ws;
+  P.lpart = P.gpart + (size_t)G * adam->n;
+  P.losses = losses_out;
+  hipStream_t st = (hipStream_t)stream;
+  EpochKernel kern = pick_tiles_kernel(P.net[0].depth == 3, A);
+  if (lds_bytes > 48 * 1024 &&
+      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess) {
+    (void)hipGetLastError();
+    trl_set_error("%s: could not raise the kernel's LDS limit", fn);
+    return TRL_EHIP;
+  }
+  hipLaunchKernelGGL(kern, dim3(2, G), dim3(NT), (size_t)lds_bytes, st, P);
+  TRL_CHECK_LAUNCH(fn);
+  // the parameters' places in the flat buffers, as segments: both networks' layers and log_std
+  Segs sg = {};
+  auto add = [&](int64_t off, int64_t len) {
+    sg.off[sg.n] = off; sg.len[sg.n] = (int)len; sg.start[sg.n + 1] = sg.start[sg.n] + (int)len; ++sg.n;
+  };
+  const trl_mlp_desc *nets[2] = {critic, actor};
+  for (int r = 0; r < 2; ++r)
+    for (int l = 0; l < nets[r]->depth; ++l) {
+      add(P.net[r].w_off[l], (int64_t)nets[r]->dims[l + 1] * nets[r]->dims[l]);
+      add(P.net[r].b_off[l], nets[r]->dims[l + 1]);
+    }
+  add(lo, A);
+  TrlAdamScalars sc = {};
+  if (update) sc = trl_adam_scalars(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->grad_scale, adam->clip_value);
+  const int total = sg.start[sg.n];
+  hipLaunchKernelGGL(k_tiles_reduce, dim3((total + 255) / 256), dim3(256), 0, st, (const float *)P.gpart, (const float *)P.lpart, G,
+                     P.n_flat, sg, adam->param, adam->grad, adam->exp_avg, adam->exp_avg_sq, sc, update ? 1 : 0, B, (int)A,
+                     losses_out);
+  TRL_CHECK_LAUNCH(fn);
+  hipLaunchKernelGGL(k_tiles_total, dim3(1), dim3(64), 0, st, losses_out, P.alpha, P.beta);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
 }

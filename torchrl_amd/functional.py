@@ -893,6 +893,35 @@ class FusedPpoLearn:
           float(alpha), float(beta), losses.data_ptr(), C.byref(a), ws.data_ptr(), _lib.stream_ptr(dev)))
     return losses
 
+  def learn_tiles(self, obs, action, returns, old_logp, adv, clip, alpha, beta, adam, update=True):
+    """One learn() step over one batch of any size through the tile pipeline spread over the chip (trl_ppo_learn_tiles):
+    the whole-step path for shapes the register-chained kernels do not take.  `adam`: the optim.FlatAdam of these
+    parameters (gradients land in its flat .grad; update=True also applies clip + Adam and advances its step count).
+    Returns the [4] loss tensor."""
+    C = self._C
+    B = obs.shape[0]
+    obs = _f32c(obs, 'obs')
+    action = _f32c(action, 'action')
+    returns = _f32c(returns, 'returns')
+    old_logp = _f32c(old_logp, 'old_log_probs')
+    adv = _f32c(adv, 'advantages')
+    if obs.dim() != 2 or obs.shape[1] != self.K0 or action.numel() != B * self.A or old_logp.numel() != B * self.A \
+        or returns.numel() != B or adv.numel() != B:
+      raise ValueError('ppo_learn_tiles: inconsistent shapes')
+    if self._ptr_key() != self._key:
+      self._bind()
+    dev = obs.device
+    lib = _lib.lib()
+    a = adam.fused_args(update)
+    ws = self._ws.get(dev, lib.trl_ppo_learn_tiles_workspace_bytes(a.n, B))
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_ppo_learn_tiles(
+          C.byref(self.descs[0]), C.byref(self.descs[1]), self.log_std.data_ptr(), obs.data_ptr(), action.data_ptr(),
+          returns.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), B, self.A, float(clip), float(alpha), float(beta),
+          losses.data_ptr(), C.byref(a), 1 if update else 0, ws.data_ptr(), _lib.stream_ptr(dev)))
+    return losses
+
   def a2c(self, obs, action, returns, alpha, beta, adam=None):
     """A2CController.learn's device work for A2CNet stacks (trl_a2c_learn_fused): a forward-only
     pass gives the detached advantage returns - V, then one launch for forward + loss + backward
