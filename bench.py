@@ -87,6 +87,8 @@ def parse(argv=None):
   ap.add_argument('--in-place', action='store_true',
                   help='dqn_atari: read the sampled frames in place out of the ring (learn_indexed(in_place=True)) instead of '
                        'gathering a dense batch first; bit-identical results, measured slower')
+  ap.add_argument('--force-gradsync', action='store_true',
+                  help='keep the gradient all-reduce in the step at world size 1 (rehearses the N-rank call sequence on one GPU)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true')
   ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -142,7 +144,7 @@ def setup_dist(args):
   torch.cuda.set_device(local % max(1, ndev))
   local = local % max(1, ndev)
   ranks_seen = 1
-  if world > 1 or os.environ.get('TRL_FORCE_GRADSYNC') == '1':
+  if world > 1 or args.force_gradsync:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     if backend == 'nccl':
@@ -156,7 +158,7 @@ def setup_dist(args):
   if args.gpus != world and rank == 0:
     print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
   args.ranks_seen = ranks_seen
-  args.backend = backend if (world > 1 or os.environ.get('TRL_FORCE_GRADSYNC') == '1') else None
+  args.backend = backend if (world > 1 or args.force_gradsync) else None
   return rank, local, world
 
 
@@ -841,6 +843,9 @@ def main(argv=None):
     # the driver's command shape: one process asked for N GPUs.  Become the launcher -- before anything GPU-side loads
     return launch_ranks(args, argv)
   _load()
+  if args.force_gradsync:
+    from torchrl_amd import config
+    config.force_gradsync = True
   if args.no_graph:
     args.graph = 'off'
   # graph replay only where the step is still BLAS + autograd: float32 frames into the flat-frame QNet

@@ -17,14 +17,21 @@
  *     off by trl_offpolicy_set_chain(0): the one-launch form of trl_ddpg_learn_fused allocates 1 KB
  *     of device memory and a ring of pinned host memory at its first call on a stream, and
  *     waits for its own launch of 16 calls back before reusing that launch's ring slot (never in
- *     practice: that launch finished long before).
+ *     practice: that launch finished long before).  Its device-wide barrier needs every workgroup of the launch
+ *     resident at once: the grid is sized from hipOccupancyMaxActiveBlocksPerMultiprocessor, every wait is bounded,
+ *     and a wait that runs out (the card is shared and a workgroup never got a CU) aborts the launch -- NaN losses,
+ *     no further update phase -- and is REPORTED: the next trl_ddpg_learn_fused call on that stream returns TRL_EHIP
+ *     naming the phase, clears the barrier block and runs that stream's later steps as one launch per phase.
  *   - thread-compatible.  Process-wide state is limited to: the thread-local error text; the
  *     mutex-guarded jump-ahead polynomial cache of trl_randperm_prefix (a pure function of the
  *     skip length, so it never changes a result); the per-device address of the static scratch
  *     array of the no-allocation entry point at the end of this header; the speculation worker of
- *     trl_randperm_prefix_ahead; the chain switch and per-stream chain state above.  Nothing reads the
- *     environment: tuning / ablation switches exist only in the -DTRL_TUNING diagnostic build
- *     (torchrl_amd/_build.py --tuning -> lib/libtrl_hip_tune.so, used by tools/ only).
+ *     trl_randperm_prefix_ahead (one helper thread, created on first use; a fork()ed child starts its own);
+ *     the chain switch and per-stream chain state above (barrier block, table ring, the pinned fault word a
+ *     timed-out barrier reports through).  Nothing reads the environment: tuning / ablation switches exist only
+ *     in the -DTRL_TUNING diagnostic build (torchrl_amd/_build.py --tuning -> lib/libtrl_hip_tune.so, used by
+ *     tools/ and by three tests' child processes); the Python layer's switches are attributes set in code
+ *     (torchrl_amd/config.py), not environment variables.
  */
 #ifndef TRL_HIP_H
 #define TRL_HIP_H

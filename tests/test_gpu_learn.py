@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from torchrl_amd import config
+
 from oracle import loss_oracle
 from torchrl_amd import functional as F
 from torchrl_amd.contrib.controllers import PPOController, A2CController
@@ -77,7 +79,7 @@ def test_fused_learn_unclipped_gradients_and_general_path(monkeypatch):
   same controller class (autograd over the fused MLP kernels + k_ppo_loss)."""
   outs = []
   for mode in ('1', '0'):
-    monkeypatch.setenv('TRL_FUSED_LEARN', mode)
+    monkeypatch.setattr(config, 'fused_learn', mode == '1')
     torch.manual_seed(11)
     ctl = PPOController(3, 2, lr=1e-3, alpha=0.5, beta=1e-3, max_grad_norm=1e9, device=DEV, hidden=(64, 64))
     assert (ctl._fused is not None) == (mode == '1')
@@ -180,7 +182,7 @@ def test_compute_return_fused_equals_general_path(monkeypatch):
   rew, last = torch.randn(T, N, generator=g).to(DEV), torch.randn(N, 3, generator=g).to(DEV)
   last_done = (torch.rand(N, generator=g) < 0.3).float().to(DEV)
   for mode in ('1', '0'):
-    monkeypatch.setenv('TRL_FUSED_LEARN', mode)
+    monkeypatch.setattr(config, 'fused_learn', mode == '1')
     torch.manual_seed(4)
     ctl = PPOController(3, 1, gamma=0.99, lmbda=0.95, device=DEV, hidden=(64, 64))
     if ctl._fused is not None:

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from torchrl_amd import config
+
 from torchrl_amd import functional as F
 from torchrl_amd.contrib import models
 
@@ -63,7 +65,7 @@ def test_mlp_container_fused_equals_plain(monkeypatch):
   gy = torch.randn(9000, 2, device=DEV)
   out = {}
   for mode in ('1', '0'):
-    monkeypatch.setenv('TRL_FUSED_MLP', mode)
+    monkeypatch.setattr(config, 'fused_mlp', mode == '1')
     net.zero_grad()
     y = net(x)
     y.backward(gy)
@@ -105,7 +107,7 @@ def test_mlp_container_uses_whole_network_path_and_matches(monkeypatch):
   x = torch.randn(20000, 3, device=DEV)
   out = {}
   for mode in ('1', '0'):
-    monkeypatch.setenv('TRL_FUSED_MLP', mode)
+    monkeypatch.setattr(config, 'fused_mlp', mode == '1')
     net.zero_grad()
     v, mean, _ = net.heads(x)
     (v.sum() + (mean * mean).sum()).backward()
@@ -117,9 +119,9 @@ def test_mlp_container_uses_whole_network_path_and_matches(monkeypatch):
     torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
   # DDPG's tanh tail stays on torch, after the fused stack
   actor = models.DDPGActorNet(3, 1, 64).to(DEV)
-  monkeypatch.setenv('TRL_FUSED_MLP', '1')
+  monkeypatch.setattr(config, 'fused_mlp', True)
   a1 = actor(x)
-  monkeypatch.setenv('TRL_FUSED_MLP', '0')
+  monkeypatch.setattr(config, 'fused_mlp', False)
   torch.testing.assert_close(a1, actor(x), rtol=1e-5, atol=1e-6)
 
 

@@ -4,7 +4,7 @@ gradient all-reduce per optimizer step; no reference counterpart -- the referenc
 With a process group present the fused step stops at the gradients (`adam=None` / `update=False`), the flat
 gradient buffer is all-reduced (RCCL when the backend is "nccl"), and a separate `trl_adam_step` applies
 1/world_size, PPO's `clip_grad_value_` (ppo_controller.py:72-73, AFTER the reduction) and Adam.  Checked here:
-  * a 1-rank RCCL group with TRL_FORCE_GRADSYNC=1 (the call sequence of an N-rank run) gives bit-identical
+  * a 1-rank RCCL group with config.force_gradsync (the call sequence of an N-rank run) gives bit-identical
     losses, clipped gradients and post-Adam weights to the single-rank in-kernel update, on the reference's own
     golden learn() fixtures for all four controllers, and meets the golden values at the usual tolerances;
   * the 1/world_size scale and the clamp are applied in that order after the reduction;
@@ -18,6 +18,8 @@ import socket
 import numpy as np
 import pytest
 import torch
+
+from torchrl_amd import config
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -50,9 +52,9 @@ def rccl_world1():
 
 def _pair(make, monkeypatch):
   """(solo, split): the same controller built without and with the gradient exchange in its step."""
-  monkeypatch.setenv('TRL_FORCE_GRADSYNC', '0')
+  monkeypatch.setattr(config, 'force_gradsync', False)
   solo = make()
-  monkeypatch.setenv('TRL_FORCE_GRADSYNC', '1')
+  monkeypatch.setattr(config, 'force_gradsync', True)
   split = make()
   assert not solo._sync.enabled and split._sync.enabled and split._sync.world_size == 1
   return solo, split
@@ -172,7 +174,7 @@ def test_ppo_scale_then_clamp_after_the_reduction(rccl_world1, monkeypatch):
   """grad_scale (1 / world_size) and clip_grad_value_ are applied to the REDUCED gradient, scale first: the update
   of a 2-rank run whose ranks hold the same half-batch gradient g is Adam on clamp(0.5 * (g + g))."""
   import copy
-  monkeypatch.setenv('TRL_FORCE_GRADSYNC', '1')
+  monkeypatch.setattr(config, 'force_gradsync', True)
   torch.manual_seed(2)
   c = PPOController(3, 2, lr=1e-3, beta=1e-3, max_grad_norm=0.01, device=DEV, hidden=(64, 64))
   assert c._sync.enabled and c._fused is not None
@@ -205,7 +207,7 @@ def test_dqn_graph_replay_with_gradient_exchange_on_the_autograd_path(rccl_world
   the graph body stops after backward, the all-reduce and Adam run outside it.  Every replay must hand them THIS
   step's gradients (round 1 advice: with detached per-parameter gradients the replays wrote into the capture's own
   tensors and the update re-used the first step's)."""
-  monkeypatch.setenv('TRL_FORCE_GRADSYNC', '1')
+  monkeypatch.setattr(config, 'force_gradsync', True)
   torch.manual_seed(4)
   eager = DQNController(1040, 4, lr=1e-3, n_update_interval=3, device=DEV, graph=False)
   graph = DQNController(1040, 4, lr=1e-3, n_update_interval=3, device=DEV, graph=True)
@@ -235,7 +237,8 @@ def test_dqn_graph_replay_with_gradient_exchange_on_the_autograd_path(rccl_world
 
 # ------------------------------------------------------------------ two real ranks (gloo, sharing the card)
 def _two_rank_worker(rank, world, port, out):
-  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TRL_FORCE_GRADSYNC='0')
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  config.force_gradsync = False
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
     dev = torch.device(DEV)
@@ -264,7 +267,7 @@ def test_two_gloo_ranks_on_half_batches_equal_the_full_batch_step():
   assert torch.equal(w0a, w0b)                              # broadcast at construction
   assert torch.equal(ga, gb) and torch.equal(wa, wb)        # same reduced gradient, same update on both ranks
   # single process, whole minibatch, same starting weights
-  os.environ['TRL_FORCE_GRADSYNC'] = '0'
+  config.force_gradsync = False
   c = PPOController(3, 1, lr=1e-3, beta=1e-3, max_grad_norm=0.5, device=DEV, hidden=(64, 64))
   c._flat.data.copy_(w0a.to(DEV))
   gen = torch.Generator().manual_seed(77)

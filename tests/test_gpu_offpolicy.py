@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 import torch
 
+from torchrl_amd import config
+
 from oracle import loss_oracle
 from torchrl_amd.contrib.controllers import DDPGController, DQNController
 
@@ -105,7 +107,7 @@ def test_ddpg_fused_vs_autograd_path_three_steps(monkeypatch):
   rs = np.random.RandomState(5)
   torch.manual_seed(5)
   fused = DDPGController(3, 1, -2.0, 2.0, device=DEV)
-  monkeypatch.setenv('TRL_FUSED_LEARN', '0')
+  monkeypatch.setattr(config, 'fused_learn', False)
   plain = DDPGController(3, 1, -2.0, 2.0, device=DEV)
   assert fused._fused is not None and plain._fused is None
   for a, b in ((fused._actor, plain._actor), (fused._critic, plain._critic),

@@ -294,3 +294,20 @@ def test_act_rng_streams_differ_per_instance_and_rank():
   x, y = F.ActRng(rank=0), F.ActRng(rank=0)
   y._instance = x._instance
   assert x.next() == y.next()
+
+
+def test_python_layer_reads_no_environment_switches():
+  """The product's path is never changed through the environment (round-2 finding: TRL_FUSED_LEARN & co. silently switched
+  kernels): the only os.environ read under torchrl_amd/ is TRL_LIB in _lib.py (which build of the library to load) and
+  the compiler lookup of _build.py."""
+  import re
+  root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'torchrl_amd')
+  hits = []
+  for d, _, files in os.walk(root):
+    for f in files:
+      if f.endswith('.py'):
+        for i, line in enumerate(open(os.path.join(d, f)), 1):
+          if re.search(r'os\.environ|getenv', line) and not line.lstrip().startswith('#'):
+            hits.append((os.path.relpath(os.path.join(d, f), root), i, line.strip()))
+  allowed = {'_lib.py', '_build.py'}
+  assert all(h[0] in allowed for h in hits), [h for h in hits if h[0] not in allowed]

@@ -29,7 +29,8 @@ def main():
   B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
   rs = np.random.RandomState(0)
   for fused in ('1', '0'):
-    os.environ['TRL_FUSED_LEARN'] = fused
+    from torchrl_amd import config
+    config.fused_learn = fused == '1'
     ctl = DDPGController(3, 1, -2.0, 2.0, device=DEV)
     batch = [torch.from_numpy(rs.randn(B, k).astype(np.float32)).to(DEV) for k in (3, 1, 1, 3, 1)]
     wall, host = timeit(lambda: ctl.learn(*batch))

@@ -45,7 +45,8 @@ def main():
           ('sample_device + learn', lambda: ctl.learn(*ds.sample_device(B)))]
   for zc in ('1', '0'):
     def samp(zc=zc):
-      os.environ['TRL_INDEX_ZERO_COPY'] = zc
+      from torchrl_amd import config
+      config.index_zero_copy = zc == '1'
       return ds.sample(B)
     rows.append(('sample zero_copy=%s' % zc, samp))
     rows.append(('sample zero_copy=%s + learn' % zc, lambda samp=samp: ctl.learn(*samp())))

@@ -4,6 +4,7 @@ import os
 import torch
 
 from ...controllers import Controller
+from ... import config
 from ... import functional as F
 from ..models import A2CNet
 from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
@@ -13,7 +14,7 @@ class A2CController(Controller):
   def __init__(self, obs_size, action_size,
                gamma=0.99, lmbda=1.0, lr=1e-3,
                alpha=0.5, beta=1.0, device=None,
-               hidden=256, process_group=None, graph=False):
+               hidden=256, process_group=None, graph=False, fused=None):
     self.device = resolve_device(device)
 
     self.ac_net = A2CNet(obs_size, action_size, hidden).to(self.device)
@@ -23,8 +24,8 @@ class A2CController(Controller):
     self.ac_net_optim = FlatAdam(self._flat, lr=lr, grad_scale=self._sync.scale, device_state=graph)
     for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
       stack.direct_grads = True
-    self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); TRL_FUSED_LEARN=0 disables
-    if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+    self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); config.fused_learn = False / fused=False disables
+    if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
       if F.FusedPpoLearn.supports(lins[0], lins[1], None):
         self._fused = F.FusedPpoLearn(lins[0], lins[1], None)

@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 from ...controllers import Controller
+from ... import config
 from ... import functional as F
 from ..models import DDPGActorNet, DDPGCriticNet
 from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
@@ -55,7 +56,7 @@ class DDPGController(Controller):
                action_low, action_high,
                actor_lr=1e-4, critic_lr=1e-3, gamma=0.99,
                tau=1e-2, n_reset_interval=100, device=None,
-               hidden=256, huber_delta=None, process_group=None, graph=False):
+               hidden=256, huber_delta=None, process_group=None, graph=False, fused=None):
     self.device = resolve_device(device)
     self.action_low = action_low
     self.action_high = action_high
@@ -80,9 +81,9 @@ class DDPGController(Controller):
                             graph and not self._sync.enabled)
 
     # the whole step as 10 phases in one launch, or 10 launches (csrc/trl_offpolicy.hip) for two-hidden-layer stacks (eager, or captured once and replayed with graph=True: the Adam step counts then live on the device);
-    # TRL_FUSED_LEARN=0 keeps the autograd path
+    # config.fused_learn = False / fused=False keeps the autograd path
     self._fused = None
-    if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+    if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in net.net if isinstance(m, torch.nn.Linear)]
               for net in (self.actor, self.critic, self.target_actor, self.target_critic)]
       if F.FusedDdpgLearn.supports(*lins):

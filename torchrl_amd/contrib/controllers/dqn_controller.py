@@ -12,6 +12,7 @@ import torch
 
 from ...controllers import Controller
 from ...utils.schedule import ExpDecaySchedule
+from ... import config
 from ... import functional as F
 from ..models import QNet, _fusable_stack
 from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
@@ -36,7 +37,7 @@ class DQNController(Controller):
                double_dqn=False, gamma=.99, lr=1e-3,
                eps_max=1.0, eps_min=1e-2, n_eps_anneal=1000,
                n_update_interval=5, device=None,
-               huber_delta=None, hidden=128, process_group=None, graph=False):
+               huber_delta=None, hidden=128, process_group=None, graph=False, fused=None):
     self.action_size = action_size
     self.device = resolve_device(device)
 
@@ -60,9 +61,9 @@ class DQNController(Controller):
     self._run = LearnRunner(self._learn_body, [self.q_net_optim], lambda: [], self.device, graph)
 
     # the step up to Adam as 6 launches (csrc/trl_offpolicy.hip) for two-hidden-layer Q-networks up
-    # to 1024 wide / fan-in (any fan-in for uint8 frames), eager or graph-replayed; TRL_FUSED_LEARN=0 keeps the autograd path
+    # to 1024 wide / fan-in (any fan-in for uint8 frames), eager or graph-replayed; config.fused_learn = False / fused=False keeps the autograd path
     self._fused = None
-    if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+    if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in net.net if isinstance(m, torch.nn.Linear)] for net in (self.q_net, self.target_q_net)]
       if F.FusedDqnLearn.supports(*lins):
         self._fused = F.FusedDqnLearn(*lins, self._q, self._target)

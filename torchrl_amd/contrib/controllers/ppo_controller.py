@@ -5,6 +5,7 @@ import os
 import torch
 
 from ...controllers import Controller
+from ... import config
 from ... import functional as F
 from ..models import ActorCriticNet
 from ._common import resolve_device, need_hip, obs_to_tensor, FlatParams, FlatAdam, GradSync, LearnRunner
@@ -17,7 +18,7 @@ class PPOController(Controller):
                gamma=0.99, lmbda=1.0, lr=1e-3,
                alpha=0.5, beta=1.0, clip_ratio=0.2,
                max_grad_norm=1.0, device=None,
-               hidden=256, process_group=None, graph=False):
+               hidden=256, process_group=None, graph=False, fused=None):
     self.device = resolve_device(device)
 
     self.ac_net = ActorCriticNet(obs_size, action_size, hidden).to(self.device)
@@ -31,8 +32,8 @@ class PPOController(Controller):
     for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
       stack.direct_grads = True
     self._epoch = None
-    self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); TRL_FUSED_LEARN=0 disables
-    if self.device.type == 'cuda' and os.environ.get('TRL_FUSED_LEARN', '1') != '0':
+    self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); config.fused_learn = False / fused=False disables
+    if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
       if F.FusedPpoLearn.supports(lins[0], lins[1], self.ac_net.log_std):
         self._fused = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)

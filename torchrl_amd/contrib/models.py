@@ -95,7 +95,7 @@ class _Mlp(nn.Sequential):
   FUSED_MAX_WIDTH wide (measured on MI355X at B = 65536: 64x64 forward 16 us vs 23 us, backward
   45 us vs ~55 us for torch with the split-K weight gradient; at 128 and above, and for small
   batches, torch's kernels are as fast or faster, so those layers stay on the torch modules).
-  CPU tensors, fan-out > 256 and TRL_FUSED_MLP=0 always take the plain modules."""
+  CPU tensors, fan-out > 256 and config.fused_mlp = False always take the plain modules."""
 
   FUSED_MIN_BATCH = 8192
   FUSED_MAX_WIDTH = 64
@@ -224,7 +224,8 @@ _Mlp._whole_net = _whole_net
 
 
 def _fused_mlp_enabled():
-  return os.environ.get('TRL_FUSED_MLP', '1') != '0'
+  from .. import config
+  return config.fused_mlp
 
 
 def _mlp(n_in, hidden_sizes, n_out, tail=None):

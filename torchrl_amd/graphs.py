@@ -18,7 +18,8 @@ import torch
 
 
 def _trace(msg):
-  if os.environ.get('TRL_GRAPH_TRACE'):
+  from . import config
+  if config.graph_trace:
     print('[graph pid %d] %s' % (os.getpid(), msg), file=sys.stderr, flush=True)
 
 

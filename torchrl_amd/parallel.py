@@ -20,12 +20,12 @@ class GradSync:
   """Sums flat gradient buffers across ranks; `scale` is what the update must multiply by."""
 
   def __init__(self, process_group=None):
-    import os
+    from . import config
     self.group = process_group
     ready = dist.is_available() and dist.is_initialized()
-    # TRL_FORCE_GRADSYNC=1 keeps the collective in the step at world_size 1, so that a one-GPU box
+    # config.force_gradsync keeps the collective in the step at world_size 1, so that a one-GPU box
     # can rehearse the RCCL call sequence (stream ordering against replayed HIP graphs)
-    force = ready and os.environ.get('TRL_FORCE_GRADSYNC', '0') == '1'
+    force = ready and bool(config.force_gradsync)
     self.enabled = ready and (dist.get_world_size(process_group) > 1 or force)
     self.world_size = dist.get_world_size(process_group) if self.enabled else 1
     self.scale = 1.0 / self.world_size
@@ -33,12 +33,11 @@ class GradSync:
     # device and the host never waits.  gloo stages device tensors through the host; an all-reduce
     # issued behind replayed HIP graphs was seen to stall there unless the compute stream is
     # drained first, so for non-RCCL backends (CPU rehearsal of the N-rank path) the drain stays.
-    # TRL_ASYNC_ALLREDUCE=0 / 1 overrides either way.
+    # config.async_allreduce = False / True overrides either way.
     backend = dist.get_backend(process_group) if self.enabled else ''
     drain = backend != 'nccl'
-    env = os.environ.get('TRL_ASYNC_ALLREDUCE')
-    if env is not None:
-      drain = env != '1'
+    if config.async_allreduce is not None:
+      drain = not config.async_allreduce
     self._host_staged = self.enabled and drain
 
   def broadcast_params(self, *flats, src=0):

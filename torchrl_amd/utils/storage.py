@@ -28,6 +28,7 @@ import torch
 from torch.utils.data import Dataset
 
 from .. import _lib
+from .. import config
 from .sampler import randperm_prefix
 
 Transition = namedtuple('Transition', ['obs', 'action', 'reward', 'next_obs', 'done'])
@@ -294,7 +295,7 @@ class TensorTupleDataset(Dataset):
       for a, off, nb in zip(cols, self._layout.offsets, self._layout.col_bytes):
         recn[:, off:off + nb] = a[lo:lo + n].view(np.uint8).reshape(n, nb)
       t0 = (tail + lo) % self._capacity
-      if n * st <= self._KERNEL_PUSH_BYTES and os.environ.get('TRL_KERNEL_PUSH', '1') != '0':
+      if n * st <= self._KERNEL_PUSH_BYTES and config.kernel_push:
         # the per-env-step case: the push kernel reads the packed records straight out of the pinned
         # buffer (one launch, wrap included).  An async H2D copy of a few hundred bytes is a DMA-engine
         # job with a cross-queue dependency on either side: ~175 us of stall in the learner's stream.
@@ -384,7 +385,7 @@ class TensorTupleDataset(Dataset):
       ev.synchronize()            # the launch issued 4 calls ago has long finished
     buf[:n].copy_(index)
     self._pin_used[slot] = True
-    if zero_copy and n <= self.ZERO_COPY_MAX_ROWS and os.environ.get('TRL_INDEX_ZERO_COPY', '1') != '0':
+    if zero_copy and n <= self.ZERO_COPY_MAX_ROWS and config.index_zero_copy:
       return buf[:n], ev          # pinned host memory is mapped into the device's address space
     idx = torch.empty(n, dtype=torch.int64, device=self._device)
     with torch.cuda.device(self._device):
