@@ -75,7 +75,7 @@ def parse(argv=None):
   ap.add_argument('--only', default=None,
                   help='run ONE kernel-timing entry and print its JSON (for a rocprofv3 kernel trace that holds nothing else): '
                        'gae_cold_blocked, gae_warm_blocked, gae_cold_tn, gae_warm_tn, gather_wide_1024, gather_wide_256, '
-                       'gather_narrow_65536, gather_narrow_128, learn_kernel')
+                       'gather_narrow_65536, gather_narrow_128, learn_kernel, learn_epoch, learn_epoch_256')
   ap.add_argument('--no-sweep', action='store_true', help='ppo: skip the minibatch sweep (64 / 65,536 / 1,048,576)')
   ap.add_argument('--sampler', default='mt19937', choices=['mt19937', 'device'],
                   help='off-policy loops: mt19937 = bit-exact torch.randperm prefix on the host (parity mode); '
@@ -213,7 +213,7 @@ def kernel_time_us(launch, iters):
   return a.elapsed_time(b) * 1e3 / iters
 
 
-PMC_FILES = ('r02_pmc_traffic.json', 'r01f_pmc_traffic.json')
+PMC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01f_pmc_traffic.json')
 
 
 def pmc_traffic(key):
@@ -289,7 +289,7 @@ def gae_roofline(args, dev, T, N, layout, warm=False, with_ceilings=True):
                      'cold in HBM (%d rotating buffer sets)' % nsets),
                   traffic_key=key if (T, N) == (2048, 4096) else None)
   roof['entry'] = key
-  roof['profile'] = 'profiles/r02_%s_kernel_stats.csv' % key
+  roof['profile'] = 'profiles/r03_%s_kernel_stats.csv' % key
   if with_ceilings:
     def copy_torch():      # a plain device copy moving the same bytes over the same rotating sets (two launches)
       s = sets[rot['i'] % nsets]
@@ -515,6 +515,15 @@ def learn_kernel_roofline(args, ctl, cols, Bk):
   f = ctl._fused
   o, a, r, l, ad = (c[:Bk].contiguous() for c in cols)
   us_l = kernel_time_us(lambda: f(o, a, r, l, ad, 0.2, 0.5, 1e-3), max(10, args.kernel_iters // 2))
+  # the spread over single launch pairs (events around each): the graph figure above is their mean without host gaps
+  singles = []
+  for _ in range(12):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    f(o, a, r, l, ad, 0.2, 0.5, 1e-3)
+    e1.record()
+    torch.cuda.synchronize()
+    singles.append(e0.elapsed_time(e1) * 1e3)
   flops = 0
   for lin in (f.critic_lin, f.actor_lin):
     for i, m in enumerate(lin):
@@ -523,8 +532,12 @@ def learn_kernel_roofline(args, ctl, cols, Bk):
   tf = flops / (us_l * 1e-6) / 1e12
   out = {'kernel': 'k_ac_learn+k_learn_reduce', 'bound': 'mfma', 'achieved': round(tf, 1),
          'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
-         'us_per_launch': round(us_l, 2), 'flops_per_launch': int(flops), 'entry': 'learn_kernel',
-         'profile': 'profiles/r02_learn_kernel_kernel_stats.csv',
+         'us_per_launch': round(us_l, 2), 'us_single_launch_pairs': {'mean': round(sum(singles) / len(singles), 2),
+                                                                     'min': round(min(singles), 2), 'max': round(max(singles), 2),
+                                                                     'note': 'events around each of 12 eager launch pairs (host gap between the two launches included); '
+                                                                             'us_per_launch / frac are the mean of graph-replayed pairs'},
+         'flops_per_launch': int(flops), 'entry': 'learn_kernel',
+         'profile': 'profiles/r03_learn_kernel_kernel_stats.csv',
          'note': 'forward + PPO loss + backward of critic and actor over one minibatch of %d '
                  '(exact f32 MFMA); %d FLOP per sample' % (Bk, flops // Bk)}
   if len(f.critic_lin) == 2:
@@ -666,7 +679,7 @@ def gather_roofline(dev, iters, rows, B, atari):
                % (row_bytes, B, rows, rows * ds.row_bytes / 1e9), traffic_key=key)
   r['transitions_per_sec'] = round(B / (us * 1e-6), 1)
   r['entry'] = 'gather_%s_%d' % ('wide' if atari else 'narrow', B)
-  r['profile'] = 'profiles/r02_%s_kernel_stats.csv' % r['entry']
+  r['profile'] = 'profiles/r03_%s_kernel_stats.csv' % r['entry']
   del ds
   torch.cuda.empty_cache()
   return r
@@ -763,7 +776,7 @@ def bench_offpolicy(args, rank, world, dev, atari):
       'config': {'workload': wl, 'minibatch': B, 'capacity': cap, 'sampler': 'mt19937 randperm prefix on the host (bit-exact; the next draw computed ahead on a helper thread, trl_randperm_prefix_ahead)' if args.sampler == 'mt19937' else
                  'philox on the device (throughput mode, not index-identical to torch.randperm)',
                  'parallelism': 'dp%d' % world, 'name': name,
-                 'gemm_selection': 'blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)',
+                 'gemm_selection': 'none (the step calls no BLAS GEMM: fused chains)' if getattr(ctl, '_fused', None) is not None else ('blas default' if args.no_gemm_tuning else 'pytorch tunableop (measured per shape)'),
                  'learn_step': 'hip-graph replay' if args.use_graph else
                  (('eager, whole step in %d launches (csrc/trl_offpolicy.hip)%s' % (9 if not args.f32_frames else 6,
                    '; frames read in place out of the ring (learn_indexed: no gathered batch)' if in_place else '')) if atari
@@ -833,6 +846,21 @@ def run_only(args, dev):
             torch.randn(n, 1, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g) - 1.0,
             torch.randn(n, 1, device=dev, generator=g))
     return learn_kernel_roofline(args, ctl, cols, n)
+  if e.startswith('learn_epoch'):
+    # `--only learn_epoch` / `learn_epoch_256`: one k_ppo_epoch launch over 4096 consecutive minibatches of 64 (--minibatch
+    # overrides) on the bench's network / the reference's 256-wide one -- the process a kernel trace of that launch is taken from
+    if e.endswith('_256'):
+      args.hidden = '256'
+    ctl, _ = make_ppo_controller(args, dev)
+    Bm, K = args.minibatch or 64, 4096
+    n = Bm * K
+    g = torch.Generator(device=dev).manual_seed(1)
+    cols = (torch.randn(n, 3, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g),
+            torch.randn(n, 1, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g) - 1.0,
+            torch.randn(n, 1, device=dev, generator=g))
+    row = learn_epoch_row(args, ctl, cols, n, Bm, 0.0, K)
+    row.update(entry=e, kernel='k_ppo_epoch', minibatch=Bm, minibatches_per_launch=K, hidden=args.hidden)
+    return row
   raise SystemExit('unknown --only entry %r' % e)
 
 
