@@ -25,10 +25,11 @@ out = (C.c_ulonglong * 32)()
 lib = _lib.lib()
 lib.trl_tune_epoch_stamps.argtypes = [C.c_void_p]
 assert lib.trl_tune_epoch_stamps(out) == 0
-names = ['layer 0', 'layer 1', '(barrier)', 'last layer dots', 'loss (wave 0)', 'lane=feature pass', 'dW1', 'g1', "dW0'", 'store x',
-         'partials + loss sums', 'small-vector Adam', 'tile Adam', 'barrier']
+names = ['layer 0 (+ barrier)', 'layer 1 + last-layer dots (+ barrier)', 'loss, wave 0 (+ barrier)', 'lane = feature pass (+ barrier)', 'dW1',
+         'g1 (+ barrier)', "dW0'", 'input swap', 'gradient / partial / loss-sum flush (+ barrier)', 'small-vector Adam', 'layer-0 Adam',
+         'W1 tile Adam', 'barrier']
 for role in range(2):
   st = [out[role * 16 + j] for j in range(14)]
   print('critic' if role == 0 else 'actor', 'total cycles (s_memtime ticks):', st[13] - st[0])
   for j in range(13):
-    print('  %-22s %6d' % (names[j], st[j + 1] - st[j]))
+    print('  %-48s %6d' % (names[j], st[j + 1] - st[j]))
