@@ -87,6 +87,9 @@ def parse(argv=None):
   ap.add_argument('--in-place', action='store_true',
                   help='dqn_atari: read the sampled frames in place out of the ring (learn_indexed(in_place=True)) instead of '
                        'gathering a dense batch first; bit-identical results, measured slower')
+  ap.add_argument('--products', default='f32', choices=['f32', 'bf16x6'],
+                  help="ppo / a2c: the whole-step kernel's 64 x 64 products: exact f32 MFMA (parity mode) or bf16 MFMA on exactly "
+                       "split operands (f32-equivalent, csrc/trl_learn.hip k_ac_learn_pair_bx)")
   ap.add_argument('--force-gradsync', action='store_true',
                   help='keep the gradient all-reduce in the step at world size 1 (rehearses the N-rank call sequence on one GPU)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -322,7 +325,7 @@ def make_ppo_controller(args, dev):
   hidden = tuple(int(h) for h in args.hidden.split(','))
   torch.manual_seed(0)
   return PPOController(3, 1, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3, clip_ratio=0.2, max_grad_norm=1.0,
-                       device=dev, hidden=hidden, graph=args.use_graph), hidden
+                       device=dev, hidden=hidden, graph=args.use_graph, products=args.products), hidden
 
 
 def bench_ppo(args, rank, world, dev):

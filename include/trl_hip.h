@@ -380,6 +380,32 @@ int trl_a2c_learn_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         double alpha, double beta, float *losses_out, float *const *critic_grads,
                         float *const *actor_grads, const trl_adam_args *adam, void *ws, void *stream);
 
+/* trl_ppo_learn_fused / trl_a2c_learn_fused with the step's 64 x 64 products (layer 1 forward, its weight gradient, its
+ * input gradient: ppo_controller.py:55-70 / a2c_controller.py:47-66 through models.py:112-147's hidden layers) on the
+ * bf16 matrix instruction.  Both operands of a product are split EXACTLY into three bf16 parts (8 + 8 + 8 significant
+ * bits) and six of the nine partial products are kept, each exact, summed in f32 accumulators: the result is within
+ * 1.2e-7 x sum |a_k| |b_k| of the exact dot product plus the f32 rounding of the sum -- the accuracy class of an f32 dot
+ * product in another summation order ("f32-equivalent"), NOT the bits of trl_ppo_learn_fused, which stays the parity
+ * mode.  Same arguments, workspace and outputs.  Shapes: the role-split kernel's only -- depth 3, hidden widths <= 64,
+ * at most 4 observations, A <= 2 (any B; the Python layer
+ * takes it from 32768 rows on, where the role-split kernel is the exact path's choice too); anything else is TRL_EINVAL.  Everything
+ * outside the three products (layer 0, last layer, loss, layer-0 gradient, reduction, clip, Adam) is the exact entry
+ * point's arithmetic.  No counterpart in the reference (which computes in f32 on the host). */
+int trl_ppo_learn_fused_bx6(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                            const float *obs, const float *action, const float *returns, const float *old_logp,
+                            const float *adv, int64_t B, int32_t A, double clip, double alpha, double beta,
+                            float *losses_out, float *const *critic_grads, float *const *actor_grads,
+                            float *dlog_std, const trl_adam_args *adam, void *ws, void *stream);
+int trl_a2c_learn_fused_bx6(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *obs,
+                            const float *action, const float *returns, const float *adv, int64_t B, int32_t A,
+                            double alpha, double beta, float *losses_out, float *const *critic_grads,
+                            float *const *actor_grads, const trl_adam_args *adam, void *ws, void *stream);
+
+/* Test surface of the two entry points above: y[64][n] = w[64][64] x[64][n] (row-major device arrays) computed with
+ * exactly their operand split, partial products and accumulation order, so that the product's error can be bounded
+ * against float64 on adversarial inputs without a network around it.  No counterpart in the reference. */
+int trl_bx6_product_probe(const float *w, const float *x, float *y, int64_t n, void *stream);
+
 /* The forward alone of the same networks over B rows, only the outputs written: the value /
  * mean / log-prob pass of PPOController.compute_return (ppo_controller.py:34, 48) and act().
  *   value [B] (needs critic), mean [B, A], logp [B, A] = Normal(mean, exp(log_std)).log_prob(action)

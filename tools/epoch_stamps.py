@@ -21,7 +21,7 @@ cols = [torch.randn(n, 3, device=dev), torch.randn(n, 1, device=dev), None, None
 for _ in range(2):
   ctl.learn_epoch(cols, B, 1)
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 256)()
 lib = _lib.lib()
 lib.trl_tune_epoch_stamps.argtypes = [C.c_void_p]
 assert lib.trl_tune_epoch_stamps(out) == 0
@@ -29,7 +29,8 @@ names = ['layer 0 (+ barrier)', 'layer 1 + last-layer dots (+ barrier)', 'loss, 
          'g1 (+ barrier)', "dW0'", 'input swap', 'gradient / partial / loss-sum flush (+ barrier)', 'small-vector Adam', 'layer-0 Adam',
          'W1 tile Adam', 'barrier']
 for role in range(2):
-  st = [out[role * 16 + j] for j in range(14)]
-  print('critic' if role == 0 else 'actor', 'total cycles (s_memtime ticks):', st[13] - st[0])
+  st = [[out[(role * 8 + w) * 16 + j] for j in range(14)] for w in range(8)]
+  print('critic' if role == 0 else 'actor', 'total cycles (s_memtime ticks), wave 0:', st[0][13] - st[0][0])
+  print('  %-48s %s' % ('phase \\ wave', ' '.join('%6d' % w for w in range(8))))
   for j in range(13):
-    print('  %-48s %6d' % (names[j], st[j + 1] - st[j]))
+    print('  %-48s %s' % (names[j], ' '.join('%6d' % (st[w][j + 1] - st[w][j]) for w in range(8))))

@@ -10,6 +10,12 @@ library computes.
   fused_learn      controllers built while it is True take the whole-step kernels (csrc/trl_learn.hip, trl_offpolicy.hip,
                    trl_epoch.hip) where their networks allow; False: the layer-by-layer / autograd path.  A controller's
                    own `fused=` argument overrides it.
+  learn_products   'f32' (default, the parity mode): the whole-step PPO / A2C kernels multiply on the exact-f32 MFMA.
+                   'bf16x6': where the role-split kernel applies (two hidden layers <= 64 wide, <= 4 observations, <= 2
+                   actions, batches >= 32,768) its three 64 x 64 products per network run on the bf16 MFMA with both operands
+                   split exactly into three bf16 parts and six of the nine partial products kept (f32 accumulators): the
+                   accuracy class of an f32 dot product, not the same bits (csrc/trl_learn.hip, k_ac_learn_pair_bx).  A
+                   controller's own `products=` argument overrides it.
   fused_mlp        Linear(+ReLU) stacks use the MFMA layer kernels (csrc/trl_mlp.hip) where they win; False: torch's.
   force_gradsync   keep the gradient all-reduce in the step at world size 1 (rehearses the N-rank call sequence on one GPU).
   async_allreduce  None: stream-ordered collective with RCCL, blocking with gloo; True / False forces either.
@@ -19,6 +25,7 @@ library computes.
 """
 
 fused_learn = True
+learn_products = 'f32'
 fused_mlp = True
 force_gradsync = False
 async_allreduce = None

@@ -14,7 +14,7 @@ class A2CController(Controller):
   def __init__(self, obs_size, action_size,
                gamma=0.99, lmbda=1.0, lr=1e-3,
                alpha=0.5, beta=1.0, device=None,
-               hidden=256, process_group=None, graph=False, fused=None):
+               hidden=256, process_group=None, graph=False, fused=None, products=None):
     self.device = resolve_device(device)
 
     self.ac_net = A2CNet(obs_size, action_size, hidden).to(self.device)
@@ -28,7 +28,7 @@ class A2CController(Controller):
     if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
       if F.FusedPpoLearn.supports(lins[0], lins[1], None):
-        self._fused = F.FusedPpoLearn(lins[0], lins[1], None)
+        self._fused = F.FusedPpoLearn(lins[0], lins[1], None, products=products or config.learn_products)
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma

@@ -18,7 +18,7 @@ class PPOController(Controller):
                gamma=0.99, lmbda=1.0, lr=1e-3,
                alpha=0.5, beta=1.0, clip_ratio=0.2,
                max_grad_norm=1.0, device=None,
-               hidden=256, process_group=None, graph=False, fused=None):
+               hidden=256, process_group=None, graph=False, fused=None, products=None):
     self.device = resolve_device(device)
 
     self.ac_net = ActorCriticNet(obs_size, action_size, hidden).to(self.device)
@@ -36,7 +36,7 @@ class PPOController(Controller):
     if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
       if F.FusedPpoLearn.supports(lins[0], lins[1], self.ac_net.log_std):
-        self._fused = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
+        self._fused = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std, products=products or config.learn_products)
       # the minibatch loop in one launch (learn_epoch, csrc/trl_epoch.hip) takes some shapes the whole-step kernel does not
       if self._fused is not None and self._fused.epoch_supported():
         self._epoch = self._fused

@@ -38,7 +38,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int NW = 8, NT = 64 * NW;  // wavefronts (two per SIMD: 256 registers each), threads per workgroup
 constexpr int T1 = 16 / NW;         // accumulator tiles a wave owns of a product with up to 16 output tiles
-constexpr int U0 = 4096 / NT;       // layer-0 elements a thread owns at most (256 x 16)
+constexpr int U0 = 4096 / NT;       // elements of the padded layer-0 image per thread at most (256 x 16)
+constexpr int G0 = U0 / 4;          // groups of four layer-0 parameters a thread owns at most
 constexpr int S = 64;               // samples per tile
 constexpr int LS = S + 4;           // row stride (floats) of every 64-column LDS image: 16 lanes x 16 B on 16 distinct bank quads
 constexpr int KP = 16;              // fan-in + 1 (the bias column), padded to one k round
@@ -119,9 +120,11 @@ __host__ __device__ inline Lay make_lay(const Net &n) {
   }
   L.red = take(L.nred * n.O * LS);
   L.gout = take(n.O * LS);
-  L.o_bl = n.O * L.HL;
-  L.o_b1 = L.o_bl + n.O;
-  L.o_ls = L.o_b1 + (d3 ? n.H2 : 0);
+  // the small vectors, in this order: last layer's weights [O][HL], hidden bias b1 [H2] (two hidden layers) -- both whole
+  // groups of four, updated four to a thread -- then the last layer's bias [O] and log_std [O] (actor), one to a thread
+  L.o_b1 = n.O * L.HL;
+  L.o_bl = L.o_b1 + (d3 ? n.H2 : 0);
+  L.o_ls = L.o_bl + n.O;
   L.NV = L.o_ls + (n.ls_off >= 0 ? n.O : 0);
   L.vp_p = take(L.NV);
   L.vp_m = take(L.NV);
@@ -251,11 +254,12 @@ __device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, co
   p = pp.x; g = gg.x; m = mm.x; v = vv.x;
 }
 
-#ifdef TRL_TUNING      // diagnostic build: clock stamps of wave 0 at the phase boundaries of one update (tools/epoch_stamps.py)
-__device__ unsigned long long g_epoch_stamp[2][16];
-#define STAMP(j)                                                                                 \
-  do {                                                                                           \
-    if (tid == 0 && k == K / 2 && t == 0) g_epoch_stamp[role][j] = __builtin_amdgcn_s_memtime(); \
+#ifdef TRL_TUNING      // diagnostic build: clock stamps of every wave at the phase boundaries of an update (tools/epoch_stamps.py); taken at
+                       // every update of the launch's second half so that the stamp code itself is warm, update K - 2's survive
+__device__ unsigned long long g_epoch_stamp[2][8][16];
+#define STAMP(j)                                                                                              \
+  do {                                                                                                        \
+    if (lane == 0 && k >= K / 2 && k + 1 < K && t == 0) g_epoch_stamp[role][w][j] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define STAMP(j) \
@@ -322,26 +326,48 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     }
   }
   // layer 0: the padded [H1][KP] image, element e = (row n = e >> 4, column j = e & 15); j < d0 a weight, j == d0 the
-  // bias, j > d0 padding (zero parameter, zero gradient: the update leaves it zero; it is never written back)
+  // bias, j > d0 padding (zero parameter, zero gradient, never updated, never written back).  The H1 (d0 + 1) real
+  // elements, numbered row by row, are owned four consecutive ones to a thread (group tid + u NT): one adam4 per group
+  // with all four lanes of the vector at work, and the groups of a small layer fall on the first waves only.
   const int n0e = H1 * KP;
+  const int C0 = d0 + 1, n0v = H1 * C0;
   auto w0_global = [&](int e) -> int64_t {
     const int n = e >> 4, j = e & 15;
     return j < d0 ? N.w_off[0] + (int64_t)n * d0 + j : (j == d0 ? N.b_off[0] + n : -1);
   };
-  float m0[U0], v0[U0];
+  v4f m0[G0], v0[G0];
+  int first0[G0];      // the group's first element: column j << 16 | offset n LDK + j in the padded images (w0p, gw0)
+#pragma unroll
+  for (int u = 0; u < G0; ++u) {
+    const int ce = 4 * (tid + u * NT), n = ce / C0, j = ce - n * C0;
+    first0[u] = ce < n0v ? (j << 16 | (n * LDK + j)) : 0;
+  }
+  // the offsets of group u's four elements; -1 beyond the layer
+  auto group_at = [&](int u, int at[4]) {
+    int a = first0[u] & 0xffff, j = first0[u] >> 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      at[r] = 4 * (tid + u * NT) + r < n0v ? a : -1;
+      ++j; ++a;
+      if (j == C0) { j = 0; a += LDK - C0; }
+    }
+  };
   for (int e = tid; e < H1 * LDK; e += NT) w0p[e] = 0.f;      // (the padding columns stay zero for good)
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < U0; ++u) {
-    const int e = tid + u * NT;
-    m0[u] = v0[u] = 0.f;
-    if (e < n0e) {
-      const int64_t g = w0_global(e);
-      if (g >= 0) {
-        if (!TILES) { m0[u] = P.m[g]; v0[u] = P.v[g]; }
-        w0p[(e >> 4) * LDK + (e & 15)] = P.param[g];
+  for (int u = 0; u < G0; ++u) {
+    float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+    int at[4];
+    group_at(u, at);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (at[r] >= 0) {
+        const int64_t g = w0_global((at[r] / LDK) * KP + at[r] % LDK);
+        if (!TILES) { m[r] = P.m[g]; v[r] = P.v[g]; }
+        w0p[at[r]] = P.param[g];
       }
     }
+    m0[u] = (v4f){m[0], m[1], m[2], m[3]}; v0[u] = (v4f){v[0], v[1], v[2], v[3]};
   }
   bool own0[T1];      // accumulator tiles w + NW u of dW0' [H1][KP]
   v4f acc0[T1];
@@ -349,9 +375,9 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   for (int u = 0; u < T1; ++u) { own0[u] = w + NW * u < H1 / 16; acc0[u] = (v4f){0, 0, 0, 0}; }
   // the small vectors: last layer [O][HL], its bias [O], hidden bias b1 [H2] (two hidden layers), log_std [O] (actor)
   auto vp_global = [&](int e) -> int64_t {
-    if (e < L.o_bl) return N.w_off[D3 ? 2 : 1] + e;
-    if (e < L.o_b1) return N.b_off[D3 ? 2 : 1] + (e - L.o_bl);
-    if (e < L.o_ls) return N.b_off[1] + (e - L.o_b1);
+    if (e < L.o_b1) return N.w_off[D3 ? 2 : 1] + e;
+    if (e < L.o_bl) return N.b_off[1] + (e - L.o_b1);
+    if (e < L.o_ls) return N.b_off[D3 ? 2 : 1] + (e - L.o_bl);
     return N.ls_off + (e - L.o_ls);
   };
   for (int e = tid; e < L.NV; e += NT) {
@@ -737,11 +763,11 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       float *gp = P.gpart + (size_t)blockIdx.y * P.n_flat;
       for (int e = tid; e < L.NV; e += NT) {
         float g;
-        if (e < L.o_bl) {
+        if (e < L.o_b1) {
           const int o = e / HL, n = e - o * HL;
           g = 0.f;
           for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + o) * L.HLP + n];
-        } else if (D3 && e >= L.o_b1 && e < L.o_ls) {
+        } else if (e < L.o_bl) {
           const int n = e - L.o_b1;
           g = 0.f;
           for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + O) * L.HLP + n];
@@ -772,50 +798,68 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
     const AdamV sc = {P.w1, P.beta2, P.c2, P.eps, P.clip, uni(step_k.x), uni(step_k.z), uni(step_k.y)};
     const bool last = k + 1 == K;
-    // the small vectors, spread from the far end of the workgroup (layer 0's elements start at thread 0)
-    for (int e = NT - 1 - tid; e < L.NV; e += NT) {
-      float g;
-      if (e < L.o_bl) {
-        const int o = e / HL, n = e - o * HL;
-        g = 0.f;
-        for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + o) * L.HLP + n];
-      } else if (D3 && e >= L.o_b1 && e < L.o_ls) {
-        const int n = e - L.o_b1;
-        g = 0.f;
-        for (int sr = 0; sr < L.wpb; ++sr) g += part[(sr * L.PO + O) * L.HLP + n];
-      } else {
-        g = tailg[e - L.o_bl];
+    // the small vectors, dealt from the far end of the workgroup (layer 0's groups start at thread 0): thread NT - 1 - T
+    // takes group T of four consecutive elements of [wL | b1] -- its gradient the partial planes of the lane = feature
+    // pass added in plane order -- or, behind the groups, ONE element of [bL | log_std]; one adam4 either way
+    {
+      const int T = NT - 1 - tid, nvec = L.o_bl >> 2;
+      if (T < nvec + (L.NV - L.o_bl)) {
+        const bool vec = T < nvec;
+        const int e0 = vec ? 4 * T : L.o_bl + (T - nvec);
+        v4f g4 = {0, 0, 0, 0}, p4 = {0, 0, 0, 0}, m4 = {0, 0, 0, 0}, v4 = {0, 0, 0, 0};
+        if (vec) {
+          int plane = O, n = e0 - L.o_b1;      // (b1's plane, two hidden layers)
+          if (e0 < L.o_b1) {
+            plane = 0; n = e0;
+#pragma unroll
+            for (int o = 1; o < O; ++o)
+              if (e0 >= o * HL) { plane = o; n = e0 - o * HL; }
+          }
+          v4f pl[NW];
+#pragma unroll
+          for (int sr = 0; sr < NW; ++sr)
+          {      // (always a valid address: planes beyond the layout's count read plane 0 and count as zeros)
+            const v4f x = *(const v4f *)(part + ((sr < L.wpb ? sr : 0) * L.PO + plane) * L.HLP + n);
+            pl[sr] = sr < L.wpb ? x : (v4f){0, 0, 0, 0};
+          }
+#pragma unroll
+          for (int sr = 0; sr < NW; ++sr) g4 = g4 + pl[sr];
+          p4 = *(const v4f *)(vpp + e0); m4 = *(const v4f *)(vpm + e0); v4 = *(const v4f *)(vpv + e0);
+        } else {
+          g4.x = tailg[T - nvec]; p4.x = vpp[e0]; m4.x = vpm[e0]; v4.x = vpv[e0];
+        }
+        adam4(p4, g4, m4, v4, sc);
+        if (vec) {
+          *(v4f *)(vpp + e0) = p4; *(v4f *)(vpm + e0) = m4; *(v4f *)(vpv + e0) = v4;
+          if (last) {      // the gradients the last learn() leaves behind (after clip_grad_value_)
+            float *gd = P.grad + vp_global(e0);
+            gd[0] = g4.x; gd[1] = g4.y; gd[2] = g4.z; gd[3] = g4.w;
+          }
+        } else {
+          vpp[e0] = p4.x; vpm[e0] = m4.x; vpv[e0] = v4.x;
+          if (last) P.grad[vp_global(e0)] = g4.x;
+        }
       }
-      float p = vpp[e], m = vpm[e], v = vpv[e];
-      adam1(p, g, m, v, sc);
-      vpp[e] = p; vpm[e] = m; vpv[e] = v;
-      if (last) P.grad[vp_global(e)] = g;      // the gradients the last learn() leaves behind (after clip_grad_value_)
     }
     STAMP(10);
-    // layer 0: the thread's elements four at a time (the clipped gradient goes back to gw0: the last update's is
-    // written out after the loop)
+    // layer 0: the thread's groups (the clipped gradient goes back to gw0: the last update's is written out after the loop)
 #pragma unroll
-    for (int u4 = 0; u4 < U0; u4 += 4) {
-      if (tid + u4 * NT < n0e) {
+    for (int u = 0; u < G0; ++u) {
+      if (4 * (tid + u * NT) < n0v) {
+        int at0[4];
+        group_at(u, at0);
         float pp[4], gg[4];
-        int at[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = tid + (u4 + u) * NT, ec = e < n0e ? e : tid;
-          at[u] = (ec >> 4) * LDK + (ec & 15);
-          pp[u] = w0p[at[u]]; gg[u] = gw0[at[u]];
+        for (int r = 0; r < 4; ++r) {
+          const int at = at0[r] >= 0 ? at0[r] : at0[0];
+          pp[r] = w0p[at]; gg[r] = gw0[at];
         }
         v4f p4 = {pp[0], pp[1], pp[2], pp[3]}, g4 = {gg[0], gg[1], gg[2], gg[3]};
-        v4f m4 = {m0[u4], m0[u4 + 1], m0[u4 + 2], m0[u4 + 3]}, v4 = {v0[u4], v0[u4 + 1], v0[u4 + 2], v0[u4 + 3]};
-        adam4(p4, g4, m4, v4, sc);
-        const float po[4] = {p4.x, p4.y, p4.z, p4.w}, go[4] = {g4.x, g4.y, g4.z, g4.w}, mo[4] = {m4.x, m4.y, m4.z, m4.w},
-                    vo[4] = {v4.x, v4.y, v4.z, v4.w};
+        adam4(p4, g4, m0[u], v0[u], sc);
+        const float po[4] = {p4.x, p4.y, p4.z, p4.w}, go[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (tid + (u4 + u) * NT < n0e) {
-            w0p[at[u]] = po[u]; gw0[at[u]] = go[u];
-            m0[u4 + u] = mo[u]; v0[u4 + u] = vo[u];
-          }
+        for (int r = 0; r < 4; ++r) {
+          if (at0[r] >= 0) { w0p[at0[r]] = po[r]; gw0[at0[r]] = go[r]; }
         }
       }
     }
@@ -851,12 +895,17 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     }
   }
 #pragma unroll
-  for (int u = 0; u < U0; ++u) {
-    const int e = tid + u * NT;
-    if (e < n0e) {
-      const int64_t g = w0_global(e);
-      const int at = (e >> 4) * LDK + (e & 15);
-      if (g >= 0) { P.param[g] = w0p[at]; P.m[g] = m0[u]; P.v[g] = v0[u]; P.grad[g] = gw0[at]; }
+  for (int u = 0; u < G0; ++u) {
+    const float m[4] = {m0[u].x, m0[u].y, m0[u].z, m0[u].w}, v[4] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w};
+    int at0[4];
+    group_at(u, at0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int at = at0[r];
+      if (at >= 0) {
+        const int64_t g = w0_global((at / LDK) * KP + at % LDK);
+        P.param[g] = w0p[at]; P.m[g] = m[r]; P.v[g] = v[r]; P.grad[g] = gw0[at];
+      }
     }
   }
   for (int e = tid; e < L.NV; e += NT) {
@@ -1020,8 +1069,8 @@ extern "C" int trl_tune_adam_compare(const float *p, const float *g, const float
   return hipGetLastError() == hipSuccess ? TRL_OK : TRL_EHIP;
 }
 
-extern "C" int trl_tune_epoch_stamps(unsigned long long *out_h /*[2][16]*/) {
-  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_epoch_stamp), sizeof(unsigned long long) * 32) == hipSuccess ? TRL_OK : TRL_EHIP;
+extern "C" int trl_tune_epoch_stamps(unsigned long long *out_h /*[2][8][16]*/) {
+  return hipMemcpyFromSymbol(out_h, HIP_SYMBOL(g_epoch_stamp), sizeof(unsigned long long) * 256) == hipSuccess ? TRL_OK : TRL_EHIP;
 }
 #endif
 

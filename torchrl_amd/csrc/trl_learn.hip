@@ -1721,6 +1721,562 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair(LearnArgs P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_ac_learn_pair_bx: the role-split kernel with the three 64 x 64 products of a network -- layer 1 forward, dW1, the
+// input gradient of layer 1 -- on v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_32x32x2_f32.  NOT the parity mode
+// (k_ac_learn_pair stays that, and the default): selected by the *_bx6 entry points only.
+//
+// Arithmetic.  An f32 is exactly the sum of three bf16: hi = its top 16 bits, mid = the top 16 bits of the exact
+// remainder, lo = what is then left (8 + 8 + 8 significant bits; two masks and two exact subtractions).  Both operands
+// of a product are split this way and six of the nine partial products kept,
+//   a b ~ a_lo b_hi + a_hi b_lo + a_mid b_mid + a_mid b_hi + a_hi b_mid + a_hi b_hi       (added in this order),
+// each partial product exact (8 x 8 bits) and all sums taken in the MFMA's f32 accumulators.  What is dropped
+// (a_mid b_lo + a_lo b_mid + a_lo b_lo) is at most 2^-23 |a| |b| per term, i.e. the result is within
+// 1.2e-7 sum |a_k| |b_k| of the exact dot product plus the f32 rounding of the accumulation: the error class of an f32
+// dot product in a different summation order ("f32-equivalent"), not the same bits.  One 32-cycle instruction covers
+// 16 k for a 32 x 32 tile where the f32 instruction needs eight of 64 cycles: 6 x 32 against 8 x 64 cycles.
+//
+// Layouts.  The 32 x 32 accumulator layout is the same for both instructions (lane = column, register r = row
+// feat(r, half)), and a bf16 operand is 8 consecutive k per lane (lane half h holds k = 8 h .. 8 h + 7 of a step).
+// Which k that is may be any permutation as long as both operands agree, so an accumulator is the next product's
+// operand as it stands: step s' of block kb takes registers 8 s' .. 8 s' + 7, i.e. features kb 32 + feat(8 s' + j, half),
+// and the weights' parts are laid out in LDS in that order, once per workgroup (sW1p / sW1Tp: [part][block][step][lane]
+// x 16 B, a wave's read of one operand is 1 KB contiguous).  dW1 sums over samples, the lane index of everything A
+// computes, so its operands still cross LDS: the g2 tile as in k_ac_learn_pair; h1 is NOT handed over -- wave B
+// recomputes it from the x tile, transposed (x as the A operand, W0 as the B operand of the same four f32 MFMAs:
+// lane = feature, register r = sample feat(r, half), which is exactly the sample order of the g2 rows' 16 B reads) and
+// once more in the accumulator layout for the ReLU mask.  That removes the h1^T tile (LDS: the parts are 48 KB against
+// 34 KB of f32 weights) and A's 32 transposing writes per strip.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// the top halves of two floats as one dword of two bf16: low 16 bits from a, high 16 bits from b
+__device__ __forceinline__ unsigned int bx_top2(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float bx_top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+// two floats -> one dword of each part
+__device__ __forceinline__ void bx_split2(float x0, float x1, unsigned int &hi, unsigned int &mid, unsigned int &lo) {
+  const f32x2 w = {x0, x1};
+  hi = bx_top2(w[0], w[1]);
+  const f32x2 r = w - f32x2{bx_top16(w[0]), bx_top16(w[1])};
+  mid = bx_top2(r[0], r[1]);
+  const f32x2 l = r - f32x2{bx_top16(r[0]), bx_top16(r[1])};
+  lo = bx_top2(l[0], l[1]);
+}
+// registers 8 s .. 8 s + 7 of an accumulator -> the three operands of one k step
+__device__ __forceinline__ void bx_split8(const f32x16 &v, int s, u32x4 (&part)[3]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    unsigned int hi, mid, lo;
+    bx_split2(v[8 * s + 2 * d], v[8 * s + 2 * d + 1], hi, mid, lo);
+    part[0][d] = hi; part[1][d] = mid; part[2][d] = lo;
+  }
+}
+
+// W1's parts into LDS in operand order.  sW1p [3][nb][ks][64][4 dwords]: lane (n = nb 32 + r32, half), step ks = (kb, s'):
+// W1[n][kb 32 + feat(8 s' + j, half)], j = 0 .. 7.  sW1Tp [3][kbo][ks][64][4]: lane (k = kbo 32 + r32, half), step
+// ks = (nb, s'): W1[nb 32 + feat(8 s' + j, half)][k].  Zero beyond the layer's real size.
+__device__ __forceinline__ void bx_stage_w1(const NetArgs &a, unsigned int *sW1p, unsigned int *sW1Tp, int tid) {
+  const int H1 = a.dims[1], H2 = a.dims[2];
+  constexpr int NPOS = 2 * 4 * 64 * 4;      // dword positions of one part
+  const float *w1 = a.w[1];
+  for (int pos = tid; pos < 2 * NPOS; pos += 512) {
+    const bool tr = pos >= NPOS;
+    const int q = tr ? pos - NPOS : pos;
+    const int d = q & 3, ln = (q >> 2) & 63, ks = (q >> 8) & 3, blk = q >> 10;
+    const int r32 = ln & 31, half = ln >> 5, kb = ks >> 1, sp = ks & 1;
+    const int f0 = kb * 32 + feat(8 * sp + 2 * d, half), f1 = kb * 32 + feat(8 * sp + 2 * d + 1, half);
+    const int o = blk * 32 + r32;
+    float x0, x1;
+    if (!tr) {      // row n = o, columns f0 / f1
+      x0 = (o < H2 && f0 < H1) ? w1[o * H1 + f0] : 0.f;
+      x1 = (o < H2 && f1 < H1) ? w1[o * H1 + f1] : 0.f;
+    } else {        // column k = o, rows f0 / f1
+      x0 = (f0 < H2 && o < H1) ? w1[f0 * H1 + o] : 0.f;
+      x1 = (f1 < H2 && o < H1) ? w1[f1 * H1 + o] : 0.f;
+    }
+    unsigned int hi, mid, lo;
+    bx_split2(x0, x1, hi, mid, lo);
+    unsigned int *dst = tr ? sW1Tp : sW1p;
+    dst[q] = hi; dst[NPOS + q] = mid; dst[2 * NPOS + q] = lo;
+  }
+}
+
+// out[0] (rows blk 0) and out[1] (rows blk 1) += W-parts x b-parts over the four k steps; bsrc[ks >> 1] registers
+// 8 (ks & 1) .. + 7 are the B operand of step ks.  The A operands are fetched one step ahead; the two output blocks
+// alternate so that no MFMA waits for the one before it.
+__device__ __forceinline__ void bx_product(f32x16 (&out)[2], const f32x16 (&bsrc)[2], const unsigned int *sWp, int lane) {
+  constexpr int NPOS = 2 * 4 * 64 * 4;
+  const u32x4 *base = (const u32x4 *)sWp + lane;
+  u32x4 a0[3], a1[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { a0[p] = base[(p * NPOS) / 4 + 0 * 256 + 0 * 64]; a1[p] = base[(p * NPOS) / 4 + 1 * 256 + 0 * 64]; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    u32x4 b[3];
+    bx_split8(bsrc[ks >> 1], ks & 1, b);
+    u32x4 n0[3], n1[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      n0[p] = a0[p]; n1[p] = a1[p];
+      if (ks + 1 < 4) { n0[p] = base[(p * NPOS) / 4 + 0 * 256 + (ks + 1) * 64]; n1[p] = base[(p * NPOS) / 4 + 1 * 256 + (ks + 1) * 64]; }
+    }
+    issue_fence();
+    out[0] = MFMA_BF(a0[2], b[0], out[0]); out[1] = MFMA_BF(a1[2], b[0], out[1]);
+    out[0] = MFMA_BF(a0[0], b[2], out[0]); out[1] = MFMA_BF(a1[0], b[2], out[1]);
+    out[0] = MFMA_BF(a0[1], b[1], out[0]); out[1] = MFMA_BF(a1[1], b[1], out[1]);
+    out[0] = MFMA_BF(a0[1], b[0], out[0]); out[1] = MFMA_BF(a1[1], b[0], out[1]);
+    out[0] = MFMA_BF(a0[0], b[1], out[0]); out[1] = MFMA_BF(a1[0], b[1], out[1]);
+    out[0] = MFMA_BF(a0[0], b[0], out[0]); out[1] = MFMA_BF(a1[0], b[0], out[1]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { a0[p] = n0[p]; a1[p] = n1[p]; }
+  }
+}
+
+template <int NO>
+__global__ __launch_bounds__(512) void k_ac_learn_pair_bx(LearnArgs P) {
+  constexpr int NT = 512, LDW0 = 5;
+  constexpr int XT = 4 * LDT + 4;                     // x^T tile: 4 rows (+ a dummy slot for idle prefetch lanes)
+  constexpr int NPOS = 2 * 4 * 64 * 4;                // dwords of one part of W1 in operand order
+  constexpr int OFF_B = 0;                            // b0, b1, bL
+  constexpr int OFF_WL = OFF_B + 64 + 64 + 4;
+  constexpr int OFF_W0 = OFF_WL + NO * 64;
+  constexpr int OFF_P1 = OFF_W0 + 64 * LDW0;
+  constexpr int OFF_P1T = OFF_P1 + 3 * NPOS;
+  constexpr int OFF_T = OFF_P1T + 3 * NPOS;
+  constexpr int NXB = 4;                              // x tiles in rotation
+  constexpr int PT_USED = NXB * XT + 2 * 64 * LDT + 8;     // per pair: the x tiles, g2, g1 tiles, the counters
+  constexpr int PT = PT_USED > 64 * 64 + 64 * LDT ? PT_USED : 64 * 64 + 64 * LDT;      // (the end-of-kernel sums re-use the pair regions)
+  static_assert(OFF_P1 % 4 == 0 && (NXB * XT) % 4 == 0, "16 B alignment of the operand arrays and tiles");
+  static_assert((OFF_T + 4 * PT) * 4 <= 160 * 1024, "LDS");
+  __shared__ __align__(16) float smem[OFF_T + 4 * PT];
+  float *const sB = smem + OFF_B, *const sWL = smem + OFF_WL, *const sW0 = smem + OFF_W0, *const sT = smem + OFF_T;
+  unsigned int *const sW1p = (unsigned int *)(smem + OFF_P1), *const sW1Tp = (unsigned int *)(smem + OFF_P1T);
+  static_assert(PT >= 32 * 64 && 4 * PT >= 4 * 12 * 64 + 64, "the end-of-kernel reduction re-uses the pair regions");
+
+  const int net = blockIdx.y;
+  const NetArgs &a = P.net[net];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5,
+            r32 = lane & 31;
+  const int pair = wave & 3;
+  const bool roleA = wave < 4;
+  const int K0 = a.dims[0], H1 = a.dims[1], HL = a.dims[2], NOr = a.dims[3];
+  const int64_t B = P.B;
+  const int A = P.A;
+
+  for (int e = tid; e < 64 * LDW0; e += NT) {
+    const int n = e / LDW0, k = e % LDW0;
+    sW0[e] = (n < H1 && k < K0) ? a.w[0][n * K0 + k] : 0.f;
+  }
+  for (int e = tid; e < NO * 64; e += NT) {
+    const int n = e >> 6, k = e & 63;
+    sWL[e] = (n < NOr && k < HL) ? a.w[2][n * HL + k] : 0.f;
+  }
+  for (int e = tid; e < 64 + 64 + 4; e += NT) {      // b0 (64), b1 (64), bL (4)
+    float v;
+    if (e < 64) v = e < H1 ? a.b[0][e] : 0.f;
+    else if (e < 128) v = e - 64 < HL ? a.b[1][e - 64] : 0.f;
+    else v = e - 128 < NOr ? a.b[2][e - 128] : 0.f;
+    sB[e] = v;
+  }
+  bx_stage_w1(a, sW1p, sW1Tp, tid);
+  float *sXp = sT + pair * PT;          // [NXB][XT]   x^T of the strip, in rotation
+  float *sG2 = sXp + NXB * XT;          // [64][LDT]   gradient w.r.t. layer 1's pre-activation
+  float *sG1 = sG2 + 64 * LDT;          // [64][LDT]   gradient w.r.t. layer 0's pre-activation
+  int *pub = (int *)(sG1 + 64 * LDT);   // [8]         hand-off counters:
+  //   pub[0] strips whose g2 tile is written (A)          pub[1] x tiles written (A): strips 0 .. pub[1] - 1
+  //   pub[2] strips whose g2 tile B has read               pub[3] strips whose x^T tile B is done with
+  if (roleA) {
+    for (int e = lane; e < NXB * XT; e += 64) sXp[e] = 0.f;   // rows >= K0 stay zero for good ...
+    if (K0 < 4 && lane < 32) {                                // ... but row 3, where there is room: ones (W0's column 3
+#pragma unroll                                                 // is zero, so the forward does not see them), which make
+      for (int t = 0; t < NXB; ++t) sXp[t * XT + 3 * LDT + lane] = 1.f;   // the layer-0 bias gradient a column of dW0
+    }
+    if (lane < 8) pub[lane] = 0;
+  }
+  __syncthreads();
+
+  const int64_t nstrips = (B + 31) >> 5;
+  const int64_t sstride = (int64_t)gridDim.x * 4;
+  int64_t strip = (int64_t)blockIdx.x * 4 + pair;
+  const int ksteps0 = (K0 + 1) >> 1;
+
+  float vdb0 = 0.f;                                                  // B
+  f32x4 dw0m = {0.f, 0.f, 0.f, 0.f};                                 // B: dW0[4 (lane / 4) + i][lane % 4] in element i
+  float vdb1 = 0.f, vec_wl[NO], sc[2 + 2 * NO];                      // A
+#pragma unroll
+  for (int n = 0; n < NO; ++n) vec_wl[n] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2 + 2 * NO; ++j) sc[j] = 0.f;
+  float *mine = sT + pair * PT;         // after the loops: [64][64] dW1 tile of the pair (B), then A's transposes
+
+  if (roleA) {
+    // =================================================================================== wave A: the chain
+    f32x16 dWL[NO][2];
+    float dbL[NO], s_main = 0.f, s_ent = 0.f, s_dls[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      dbL[n] = 0.f; s_dls[n] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dWL[n][kb][r] = 0.f;
+    }
+    float den[NO], var[NO], logsig[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      den[n] = var[n] = 1.f; logsig[n] = 0.f;
+      if (net == 1 && P.kind == KIND_PPO && n < A) {
+        const float sigma = expf(P.log_std[n]);   // self.log_std.exp()
+        var[n] = uni(sigma * sigma);              // scale ** 2
+        logsig[n] = uni(logf(sigma));             // scale.log()
+        den[n] = uni(2.0f * (sigma * sigma));
+      }
+    }
+    const LossConst lc{uni(1.0f / (float)B), uni(-(1.0f / (float)(B * A)))};
+    const int q64 = 64 / K0, m64 = 64 % K0;
+    constexpr int XPF = 2;               // 32 rows x fan-in <= 4: at most 128 elements
+    const int nelem = 32 * K0;
+    int xoff[XPF];
+    {
+      int rr = lane / K0, kk = lane % K0;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) {
+        xoff[j] = lane + 64 * j < nelem ? kk * LDT + rr : XT - 4;
+        rr += q64; kk += m64;
+        if (kk >= K0) { kk -= K0; ++rr; }
+      }
+    }
+    const float *in0 = net == 0 ? P.returns : P.adv;
+    const float *in_act[NO], *in_olp[NO];
+    const bool ppo_actor = net == 1 && P.kind == KIND_PPO;
+    const int astr = ppo_actor ? A : 1;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      in_act[n] = net == 0 ? in0 : (ppo_actor ? P.action + (n < A ? n : 0) : P.action);
+      in_olp[n] = ppo_actor ? P.old_logp + (n < A ? n : 0) : in0;
+    }
+    float xr[XPF], p_in0 = 0.f, p_act[NO], p_olp[NO];
+    auto fetch_x = [&](int64_t st) {     // observations of a strip
+      st = st < nstrips ? st : nstrips - 1;
+      const int64_t row0 = st << 5;
+      const int64_t left = B - row0;
+      const int rows = (int)(left < 32 ? left : 32);
+      const float *base = P.obs + row0 * K0;
+      const int last = rows * K0 - 1;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) {
+        const int e = lane + 64 * j;
+        xr[j] = base[e < last ? e : last];
+      }
+    };
+    auto fetch_p = [&](int64_t st) {     // per-row loss inputs of a strip
+      st = st < nstrips ? st : nstrips - 1;
+      const int64_t row0 = st << 5;
+      const int64_t left = B - row0;
+      const int rows = (int)(left < 32 ? left : 32);
+      const int rl = r32 < rows ? r32 : rows - 1;
+      p_in0 = (in0 + row0)[rl];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        p_act[n] = (in_act[n] + row0 * astr)[rl * astr];
+        p_olp[n] = (in_olp[n] + row0 * astr)[rl * astr];
+      }
+    };
+    // x tile of strip it + 1 is written in the middle of strip it; tile (it + 1) % NXB was last read by B in strip it - 3
+    auto put_x = [&](int slot) {
+      float *sXw = sXp + (slot % NXB) * XT;
+#pragma unroll
+      for (int j = 0; j < XPF; ++j) sXw[xoff[j]] = xr[j];
+    };
+    fetch_x(strip);
+    fetch_p(strip);
+    put_x(0);
+    pair_post(pub + 1, 1, lane);
+    fetch_x(strip + sstride);
+    for (int it = 0; strip < nstrips; strip += sstride, ++it) {
+      const int64_t row0 = strip << 5;
+      const bool valid = row0 + r32 < B;
+      float *sX = sXp + (it % NXB) * XT;      // written in the middle of the previous strip (put_x)
+      const float ret = p_in0, ad = p_in0;
+      float act[NO], olp[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) { act[n] = p_act[n]; olp[n] = p_olp[n]; }
+      fetch_p(strip + sstride);
+      wave_lds_fence();
+
+      f32x16 h1[2], h2[2];
+      float out[NO];
+      fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+      load_feat_vec(h2, sB + 64, half);
+      bx_product(h2, h1, sW1p, lane);
+      relu2(h2);
+      pair_wait(pub + 3, it - 2);             // (never blocks: see put_x)
+      put_x(it + 1);
+      pair_post(pub + 1, it + 2, lane);
+      fetch_x(strip + 2 * sstride);
+      fwd_last<NO>(out, h2, sWL, sB + 128, half);
+
+      float gout[NO];
+      loss_grad<NO>(P, net, A, valid, half, lc, out, ret, ad, act, olp, den, var, logsig, gout, s_main, s_ent, s_dls);
+#pragma unroll
+      for (int n = 0; n < NO; ++n)
+        if (half == 0) dbL[n] += gout[n];
+
+      // last layer backward (VALU): dWL partials per lane; g = (WL^T gout) * (h2 > 0)
+      f32x16 g[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};      // (two features per v_pk_fma_f32)
+#pragma unroll
+          for (int n = 0; n < NO; ++n) {
+            const float4 w4 = *(const float4 *)(sWL + n * 64 + kb * 32 + 8 * q + 4 * half);
+            t0 = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, f32x2{gout[n], gout[n]}, t0);
+            t1 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, f32x2{gout[n], gout[n]}, t1);
+          }
+          const float t[4] = {t0.x, t0.y, t1.x, t1.y};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) g[kb][4 * q + i] = h2[kb][4 * q + i] > 0.f ? t[i] : 0.f;
+        }
+      // publish g2 (B has read the previous strip's at the start of its own previous strip: never blocks)
+      pair_wait(pub + 2, it);
+      put_tile(sG2, g, half, r32);
+      pair_post(pub + 0, it + 1, lane);
+
+      // off the critical path
+#pragma unroll
+      for (int n = 0; n < NO; ++n)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dWL[n][kb][r] = fmaf(gout[n], h2[kb][r], dWL[n][kb][r]);
+      vdb1 += row_sum32(sG2 + lane * LDT);     // db1[lane]: the row of the tile this wave has just written
+    }
+    __syncthreads();      // (1) every pair is through its strips: the pair regions are free
+    float *tr = mine + 64 * 64;
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      put_tile(tr, dWL[n], half, r32);
+      wave_lds_fence();
+      float sum = 0.f;
+      for (int r = 0; r < 32; ++r) sum += tr[lane * LDT + r];
+      vec_wl[n] = sum;
+      wave_lds_fence();
+    }
+    sc[0] = trl_wave_sum(s_main);
+    sc[1] = trl_wave_sum(s_ent);
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+      sc[2 + n] = trl_wave_sum(s_dls[n]);
+      sc[2 + NO + n] = trl_wave_sum(dbL[n]);
+    }
+  } else {
+    // =================================================================================== wave B: the tiles' readers
+    f32x16 accW1[2][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW1[nb][kb][r] = 0.f;
+    const float *ga = sG2 + r32 * LDT + 4 * half;
+    const float bias0 = sB[r32], bias1 = sB[32 + r32];
+    for (int it = 0; strip < nstrips; strip += sstride, ++it) {
+      const float *sX = sXp + (it % NXB) * XT;
+      pair_wait(pub + 1, it + 1);
+      // h1 of the strip, transposed: lane = feature kb 32 + r32, register r = sample feat(r, half) -- the B operand of
+      // dW1 += g2 h1^T as three bf16 parts per k step (t = samples' registers 8 t .. 8 t + 7)
+      u32x4 Xp[2][2][3];
+      {
+        f32x16 xt[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xt[0][r] = bias0; xt[1][r] = bias1; }
+        for (int s = 0; s < ksteps0; ++s) {
+          const int k = 2 * s + half;
+          const float xv = sX[k * LDT + r32];
+          const float w0 = sW0[r32 * LDW0 + k];
+          const float w1 = sW0[(32 + r32) * LDW0 + k];
+          xt[0] = MFMA(xv, w0, xt[0]);
+          xt[1] = MFMA(xv, w1, xt[1]);
+        }
+        relu2(xt);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bx_split8(xt[kb], t, Xp[kb][t]);
+      }
+      // g2: rows (the A operand of dW1; a lane's 16 B reads are samples 8 j + 4 half + i = feat(4 j + i, half)) and in the
+      // accumulator layout (the B operand of the input-gradient product); then the tile goes back to A
+      pair_wait(pub + 0, it + 1);
+      u32x4 Gp[2][2][3];
+      f32x16 gB[2];
+      {
+        f32x16 gr[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v0 = ld4(ga + 8 * j), v1 = ld4(ga + 32 * LDT + 8 * j);
+          gr[0][4 * j] = v0.x; gr[0][4 * j + 1] = v0.y; gr[0][4 * j + 2] = v0.z; gr[0][4 * j + 3] = v0.w;
+          gr[1][4 * j] = v1.x; gr[1][4 * j + 1] = v1.y; gr[1][4 * j + 2] = v1.z; gr[1][4 * j + 3] = v1.w;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gB[kb][r] = sG2[(kb * 32 + feat(r, half)) * LDT + r32];
+        pair_post(pub + 2, it + 1, lane);         // (LDS keeps issue order: the store follows the reads above)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bx_split8(gr[nb], t, Gp[nb][t]);
+      }
+      // dW1[n][k] += sum over samples: 2 x 2 blocks x 2 steps x 6 partial products, the four accumulators in rotation
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#define BX_DW1(pa, pb)                                                          \
+  accW1[0][0] = MFMA_BF(Gp[0][t][pa], Xp[0][t][pb], accW1[0][0]);               \
+  accW1[0][1] = MFMA_BF(Gp[0][t][pa], Xp[1][t][pb], accW1[0][1]);               \
+  accW1[1][0] = MFMA_BF(Gp[1][t][pa], Xp[0][t][pb], accW1[1][0]);               \
+  accW1[1][1] = MFMA_BF(Gp[1][t][pa], Xp[1][t][pb], accW1[1][1]);
+        BX_DW1(2, 0) BX_DW1(0, 2) BX_DW1(1, 1) BX_DW1(1, 0) BX_DW1(0, 1) BX_DW1(0, 0)
+#undef BX_DW1
+      }
+      // layer 1 backward, input side: t^T = W1^T g2^T, then the mask: g1 = t * (h1 > 0), h1 recomputed in the
+      // accumulator layout (the same four MFMAs wave A ran)
+      f32x16 t[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[kb][r] = 0.f;
+      bx_product(t, gB, sW1Tp, lane);
+      {
+        f32x16 hm[2];
+        fwd_layer0<LDW0>(hm, sX, sW0, sB, ksteps0, half, r32);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[kb][r] = hm[kb][r] > 0.f ? t[kb][r] : 0.f;
+      }
+      put_tile(sG1, t, half, r32);
+      wave_lds_fence();
+      // layer 0: dW0[n][k] += sum_row g1[n][row] x[k][row] as 32 one-step products of v_mfma_f32_4x4x1
+      {
+        const float *grow = sG1 + lane * LDT, *xrow = sXp + (it % NXB) * XT + (lane & 3) * LDT;
+        float4 gv[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gv[i] = ld4(grow + 4 * i); xv[i] = ld4(xrow + 4 * i); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dw0m = __builtin_amdgcn_mfma_f32_4x4x1f32(f4(gv[i], c), f4(xv[i], c), dw0m, 0, 0, 0);
+        if (K0 == 4) {
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { s0 += gv[i].x; s1 += gv[i].y; s2 += gv[i].z; s3 += gv[i].w; }
+          vdb0 += (s0 + s1) + (s2 + s3);
+        }
+      }
+      pair_post(pub + 3, it + 1, lane);
+    }
+    __syncthreads();      // (1)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(nb * 32 + feat(r, half)) * 64 + kb * 32 + r32] = accW1[nb][kb][r];
+  }
+
+  // =========================================================================== partials out (as k_ac_learn_pair)
+  __syncthreads();        // (2)
+  float *part = P.ws + ((int64_t)net * gridDim.x + blockIdx.x) * P.pstride;
+  {
+    const int N = a.dims[2], K = H1, off = a.poff[1];
+    for (int e = tid; e < N * K; e += NT) {
+      const int i = (e / K) * 64 + (e % K);
+      part[off + e] = ((sT[i] + sT[PT + i]) + sT[2 * PT + i]) + sT[3 * PT + i];
+    }
+  }
+  __syncthreads();
+  constexpr int VS = 12;     // slots: db0, db1, NO last-layer rows, 4 dW0 columns
+  float *vsum = sT, *scal = sT + 4 * VS * 64;
+  if (roleA) {
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 2 + 2 * NO; ++j) scal[pair * 16 + j] = sc[j];
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) vsum[(pair * VS + 2 + n) * 64 + lane] = vec_wl[n];
+    vsum[(pair * VS + 1) * 64 + lane] = vdb1;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vsum[(pair * VS + 2 + NO + (lane & 3)) * 64 + 4 * (lane >> 2) + i] = dw0m[i];
+    if (K0 == 4) {
+      vsum[(pair * VS + 0) * 64 + lane] = vdb0;
+    } else if ((lane & 3) == 3) {          // column 3 of the products: the ones row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vsum[(pair * VS + 0) * 64 + 4 * (lane >> 2) + i] = dw0m[i];
+    }
+  }
+  __syncthreads();
+  for (int sl = tid >> 6; sl < 2 + NO + 4; sl += 8) {
+    const int f = tid & 63;
+    const float v = ((vsum[(0 * VS + sl) * 64 + f] + vsum[(1 * VS + sl) * 64 + f]) + vsum[(2 * VS + sl) * 64 + f]) +
+                    vsum[(3 * VS + sl) * 64 + f];
+    if (sl >= 2 + NO) {
+      const int k = sl - 2 - NO;
+      if (f < H1 && k < K0) part[a.poff[0] + f * K0 + k] = v;
+    } else if (sl == 0) {
+      if (f < H1) part[a.poff[0] + H1 * K0 + f] = v;
+    } else if (sl == 1) {
+      if (f < a.dims[2]) part[a.poff[1] + a.dims[2] * H1 + f] = v;
+    } else {
+      const int n = sl - 2;
+      if (f < HL && n < NOr) part[a.poff[2] + n * HL + f] = v;
+    }
+  }
+  if (tid < 2 + 2 * NO) {
+    const float v = ((scal[0 * 16 + tid] + scal[1 * 16 + tid]) + scal[2 * 16 + tid]) + scal[3 * 16 + tid];
+    if (tid < 2 + NO) {                       // s_main, s_ent, dls[n]
+      if (tid < 2 + A) part[a.nparams + tid] = v;
+    } else {                                  // dbL[n]
+      const int n = tid - 2 - NO;
+      if (n < NOr) part[a.poff[2] + NOr * HL + n] = v;
+    }
+  }
+}
+
+// y[64][n] = w[64][64] x[64][n] through bx_stage_w1 + bx_product, i.e. exactly the operand split, partial products and
+// accumulation order of the learner's bf16x6 products (a test surface: tests/test_gpu_learn_bx6.py bounds its error
+// against float64 on cancelling inputs).  One wave per 32 columns.
+__global__ __launch_bounds__(512) void k_bx6_probe(const float *w, const float *x, float *y, int64_t n) {
+  constexpr int NPOS = 2 * 4 * 64 * 4;
+  __shared__ __align__(16) unsigned int sP[6 * NPOS];
+  NetArgs a{};
+  a.dims[1] = 64; a.dims[2] = 64; a.w[1] = w;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  bx_stage_w1(a, sP, sP + 3 * NPOS, tid);
+  __syncthreads();
+  for (int64_t c0 = ((int64_t)blockIdx.x * 8 + wave) * 32; c0 < n; c0 += (int64_t)gridDim.x * 8 * 32) {
+    const int64_t col = c0 + r32 < n ? c0 + r32 : n - 1;
+    f32x16 b[2], out[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { b[kb][r] = x[(int64_t)(kb * 32 + feat(r, half)) * n + col]; out[kb][r] = 0.f; }
+    bx_product(out, b, sP, lane);
+    if (c0 + r32 < n) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[(int64_t)(nb * 32 + feat(r, half)) * n + col] = out[nb][r];
+    }
+  }
+}
+
 struct InferArgs {
   NetArgs net[2];
   int32_t which[2];     // blockIdx.y -> network index
@@ -2156,7 +2712,7 @@ extern "C" int64_t trl_ppo_learn_workspace_bytes(const trl_mlp_desc *critic, con
 }
 
 namespace {
-int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+int learn_fused(const char *fn, int kind, bool bx6, const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
                 const float *obs, const float *action, const float *returns, const float *old_logp, const float *adv,
                 int64_t B, int32_t A, double clip, double alpha, double beta, float *losses_out,
                 float *const *critic_grads, float *const *actor_grads, float *dlog_std, const trl_adam_args *adam,
@@ -2185,7 +2741,7 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
   // two hidden layers over a fan-in <= 4 and enough strips for 2 x 1024 waves: the eight-wave variant
   const int hmax = critic->dims[1] > actor->dims[1] ? critic->dims[1] : actor->dims[1];
   // two hidden layers over a fan-in <= 4 and enough strips to keep 1024 wave pairs busy: the role-split kernel
-  bool pairk = critic->depth == 3 && critic->dims[0] <= 4 && A <= 2 && B >= 8 * 32 * 128;
+  bool pairk = critic->depth == 3 && critic->dims[0] <= 4 && A <= 2 && (bx6 || B >= 8 * 32 * 128);
   bool onewide = true;     // one hidden layer <= 64 wide over a fan-in <= 4: k_ac_learn_wide with one block
 #ifdef TRL_TUNING
   if (const char *e = getenv("TRL_LEARN_ONEWIDE")) onewide = atoi(e) != 0;       // A/B runs of tools/ only
@@ -2227,7 +2783,13 @@ int learn_fused(const char *fn, int kind, const trl_mlp_desc *critic, const trl_
     if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_learn<d, kb, no, kb == 1>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_learn<d, kb, no, false>), grid, block, 0, st, P);               \
   }
-  if (pairk) {
+  TRL_REQUIRE(!bx6 || pairk,
+              "%s: the bf16x6 products exist for the role-split kernel only: two hidden layers <= 64 wide, at most 4 "
+              "observations, at most 2 actions", fn);
+  if (pairk && bx6) {
+    if (NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair_bx<1>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_ac_learn_pair_bx<2>), grid, block, 0, st, P);
+  } else if (pairk) {
     if (NOv == 1) hipLaunchKernelGGL((k_ac_learn_pair<1>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_ac_learn_pair<2>), grid, block, 0, st, P);
   } else if (D == 2 && (hmax > 64 || (onewide && critic->dims[0] <= 4 && NOv <= 2))) {
@@ -2273,7 +2835,7 @@ extern "C" int trl_ppo_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
                                    double alpha, double beta, float *losses_out, float *const *critic_grads,
                                    float *const *actor_grads, float *dlog_std, const trl_adam_args *adam, void *ws,
                                    void *stream) {
-  return learn_fused("trl_ppo_learn_fused", KIND_PPO, critic, actor, log_std, obs, action, returns, old_logp, adv, B, A,
+  return learn_fused("trl_ppo_learn_fused", KIND_PPO, false, critic, actor, log_std, obs, action, returns, old_logp, adv, B, A,
                      clip, alpha, beta, losses_out, critic_grads, actor_grads, dlog_std, adam, ws, stream);
 }
 
@@ -2281,8 +2843,36 @@ extern "C" int trl_a2c_learn_fused(const trl_mlp_desc *critic, const trl_mlp_des
                                    const float *action, const float *returns, const float *adv, int64_t B, int32_t A,
                                    double alpha, double beta, float *losses_out, float *const *critic_grads,
                                    float *const *actor_grads, const trl_adam_args *adam, void *ws, void *stream) {
-  return learn_fused("trl_a2c_learn_fused", KIND_A2C, critic, actor, nullptr, obs, action, returns, nullptr, adv, B, A,
+  return learn_fused("trl_a2c_learn_fused", KIND_A2C, false, critic, actor, nullptr, obs, action, returns, nullptr, adv, B, A,
                      0.0, alpha, beta, losses_out, critic_grads, actor_grads, nullptr, adam, ws, stream);
+}
+
+extern "C" int trl_ppo_learn_fused_bx6(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                       const float *obs, const float *action, const float *returns,
+                                       const float *old_logp, const float *adv, int64_t B, int32_t A, double clip,
+                                       double alpha, double beta, float *losses_out, float *const *critic_grads,
+                                       float *const *actor_grads, float *dlog_std, const trl_adam_args *adam, void *ws,
+                                       void *stream) {
+  return learn_fused("trl_ppo_learn_fused_bx6", KIND_PPO, true, critic, actor, log_std, obs, action, returns, old_logp, adv,
+                     B, A, clip, alpha, beta, losses_out, critic_grads, actor_grads, dlog_std, adam, ws, stream);
+}
+
+extern "C" int trl_a2c_learn_fused_bx6(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *obs,
+                                       const float *action, const float *returns, const float *adv, int64_t B, int32_t A,
+                                       double alpha, double beta, float *losses_out, float *const *critic_grads,
+                                       float *const *actor_grads, const trl_adam_args *adam, void *ws, void *stream) {
+  return learn_fused("trl_a2c_learn_fused_bx6", KIND_A2C, true, critic, actor, nullptr, obs, action, returns, nullptr, adv,
+                     B, A, 0.0, alpha, beta, losses_out, critic_grads, actor_grads, nullptr, adam, ws, stream);
+}
+
+extern "C" int trl_bx6_product_probe(const float *w, const float *x, float *y, int64_t n, void *stream) {
+  const char *fn = "trl_bx6_product_probe";
+  TRL_REQUIRE(w && x && y, "%s: null pointer", fn);
+  TRL_REQUIRE(n > 0 && n < (1ll << 31), "%s: n=%lld out of range", fn, (long long)n);
+  const int64_t need = trl_cdiv(n, 256);
+  hipLaunchKernelGGL(k_bx6_probe, dim3((unsigned)(need < 256 ? need : 256)), dim3(512), 0, (hipStream_t)stream, w, x, y, n);
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
 }
 
 extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,

@@ -738,13 +738,19 @@ class FusedPpoLearn:
           return False
     return True
 
-  def __init__(self, critic_lin, actor_lin, log_std):
+  # batches the role-split kernel (and with it the bf16x6 products) takes: 8 x 32 x 128 rows and more
+  BX6_MIN_BATCH = 8 * 32 * 128
+
+  def __init__(self, critic_lin, actor_lin, log_std, products='f32'):
     import ctypes as C
+    if products not in ('f32', 'bf16x6'):
+      raise ValueError("products must be 'f32' or 'bf16x6'")
     self._C = C
     self.critic_lin, self.actor_lin, self.log_std = list(critic_lin), list(actor_lin), log_std
     self.A = actor_lin[-1].out_features
     self.K0 = critic_lin[0].in_features
     self.device = critic_lin[0].weight.device
+    self.products = products
     self._key = None
     self._ws = _Workspace()      # this object's own scratch (its address may be captured into a HIP graph)
     self._bind()
@@ -775,6 +781,13 @@ class FusedPpoLearn:
   def usable(self, obs):
     return obs.is_cuda and obs.dim() == 2 and obs.dtype == torch.float32 and obs.shape[0] >= self.MIN_BATCH \
         and obs.shape[1] == self.K0
+
+  def bx6_takes(self, B):
+    """True when a step over B rows runs its 64 x 64 products on the bf16 MFMA (products='bf16x6' and the shape is the
+    role-split kernel's: two hidden layers <= 64 wide over <= 4 observations, <= 2 actions, a large batch); every
+    other step of this object is the exact-f32 kernels'."""
+    return self.products == 'bf16x6' and len(self.critic_lin) == 3 and self.K0 <= 4 and self.A <= 2 \
+        and B >= self.BX6_MIN_BATCH
 
   def forward(self, obs, action=None, want_value=True, want_mean=True):
     """No-grad forward over obs [B, fan-in] writing only the outputs (trl_ppo_forward_fused):
@@ -819,8 +832,9 @@ class FusedPpoLearn:
     aref = None
     if adam is not None:
       aref = C.byref(adam.fused_args())
+    fn = lib.trl_ppo_learn_fused_bx6 if self.bx6_takes(B) else lib.trl_ppo_learn_fused
     with torch.cuda.device(dev):
-      _lib.check(lib.trl_ppo_learn_fused(
+      _lib.check(fn(
           C.byref(self.descs[0]), C.byref(self.descs[1]), self.log_std.data_ptr(), obs.data_ptr(),
           action.data_ptr(), returns.data_ptr(), old_logp.data_ptr(), adv.data_ptr(), B, self.A, float(clip),
           float(alpha), float(beta), losses.data_ptr(), self.gradp[0], self.gradp[1],
@@ -940,8 +954,9 @@ class FusedPpoLearn:
     ws = self._ws.get(dev, lib.trl_ppo_learn_workspace_bytes(C.byref(self.descs[0]), C.byref(self.descs[1]), B))
     losses = torch.empty(4, dtype=torch.float32, device=dev)
     aref = C.byref(adam.fused_args()) if adam is not None else None
+    fn = lib.trl_a2c_learn_fused_bx6 if self.bx6_takes(B) else lib.trl_a2c_learn_fused
     with torch.cuda.device(dev):
-      _lib.check(lib.trl_a2c_learn_fused(
+      _lib.check(fn(
           C.byref(self.descs[0]), C.byref(self.descs[1]), obs.data_ptr(), action.data_ptr(), returns.data_ptr(),
           adv.data_ptr(), B, self.A, float(alpha), float(beta), losses.data_ptr(), self.gradp[0], self.gradp[1],
           aref, ws.data_ptr(), _lib.stream_ptr(dev)))
