@@ -51,6 +51,7 @@ def _load():
   TensorTupleDataset = _T
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+BF16_MFMA_PEAK_TFLOPS = 2516.6   # v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense; MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (MI355X_MICROARCH.md, matrix cores)
 
 
@@ -75,7 +76,7 @@ def parse(argv=None):
   ap.add_argument('--only', default=None,
                   help='run ONE kernel-timing entry and print its JSON (for a rocprofv3 kernel trace that holds nothing else): '
                        'gae_cold_blocked, gae_warm_blocked, gae_cold_tn, gae_warm_tn, gather_wide_1024, gather_wide_256, '
-                       'gather_narrow_65536, gather_narrow_128, learn_kernel, learn_epoch, learn_epoch_256')
+                       'gather_narrow_65536, gather_narrow_128, learn_kernel, learn_kernel_bf16x6, learn_epoch, learn_epoch_256')
   ap.add_argument('--no-sweep', action='store_true', help='ppo: skip the minibatch sweep (64 / 65,536 / 1,048,576)')
   ap.add_argument('--sampler', default='mt19937', choices=['mt19937', 'device'],
                   help='off-policy loops: mt19937 = bit-exact torch.randperm prefix on the host (parity mode); '
@@ -87,7 +88,7 @@ def parse(argv=None):
   ap.add_argument('--in-place', action='store_true',
                   help='dqn_atari: read the sampled frames in place out of the ring (learn_indexed(in_place=True)) instead of '
                        'gathering a dense batch first; bit-identical results, measured slower')
-  ap.add_argument('--products', default='f32', choices=['f32', 'bf16x6'],
+  ap.add_argument('--products', default='bf16x6', choices=['f32', 'bf16x6'],
                   help="ppo / a2c: the whole-step kernel's 64 x 64 products: exact f32 MFMA (parity mode) or bf16 MFMA on exactly "
                        "split operands (f32-equivalent, csrc/trl_learn.hip k_ac_learn_pair_bx)")
   ap.add_argument('--force-gradsync', action='store_true',
@@ -321,11 +322,15 @@ def gae_roofline(args, dev, T, N, layout, warm=False, with_ceilings=True):
   return roof
 
 
-def make_ppo_controller(args, dev):
+def make_ppo_controller(args, dev, products=None):
   hidden = tuple(int(h) for h in args.hidden.split(','))
   torch.manual_seed(0)
   return PPOController(3, 1, gamma=0.99, lmbda=0.95, lr=3e-4, alpha=0.5, beta=1e-3, clip_ratio=0.2, max_grad_norm=1.0,
-                       device=dev, hidden=hidden, graph=args.use_graph, products=args.products), hidden
+                       device=dev, hidden=hidden, graph=args.use_graph, products=products or args.products), hidden
+
+
+DTYPE_NOTE = {'f32': 'f32',
+              'bf16x6': 'f32-equivalent (bf16x6 split, f32 accumulate)'}
 
 
 def bench_ppo(args, rank, world, dev):
@@ -386,6 +391,15 @@ def bench_ppo(args, rank, world, dev):
   ms_return, ms_learn = e0.elapsed_time(e1), e1.elapsed_time(e2)
   learned = args.epochs * n * steps * world
   value = learned / dt
+  # which arithmetic the 64 x 64 products of these learn() calls ran in (the bf16x6 variant exists for the role-split
+  # kernel's shapes only: everything else is the exact-f32 kernels whatever --products says)
+  bx = ctl._fused is not None and ctl._fused.bx6_takes(min(B, n))
+  products_used = 'bf16x6' if bx else 'f32'
+  products_note = ('bf16x6: the three 64 x 64 products per network (layer 1 forward, its weight and input gradients) on '
+                   'v_mfma_f32_32x32x16_bf16, both operands split exactly into three bf16 parts, six of nine partial products, '
+                   'f32 accumulators; everything else (layer 0, last layer, loss, GAE, reduction, clip, Adam) exact f32.  Not the '
+                   'parity mode: `variants.exact_f32` is the same step on the exact-f32 MFMA (products="f32", the library default)'
+                   if bx else 'f32: exact-f32 MFMA (the parity mode)')
 
   roof = gae_roofline(args, dev, T, N, args.rollout_layout)
   warm = gae_roofline(args, dev, T, N, args.rollout_layout, warm=True, with_ceilings=False)
@@ -404,8 +418,9 @@ def bench_ppo(args, rank, world, dev):
       'metric': 'learner transitions/sec (PPO: GAE + clipped loss + update)', 'value': round(value, 1),
       'unit': 'transitions/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
       'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-      'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'vs_baseline': None, 'dtype': DTYPE_NOTE[products_used], 'data': 'synthetic',
       'config': {'workload': 'ppo_gae_clip: T=%d, N_envs=%d per GPU, MLP %s, obs 3, act 1' % (T, N, args.hidden),
+                 'products': products_note,
                  'minibatch': B, 'n_epochs': args.epochs, 'learn_calls_per_step': args.epochs * ((n + B - 1) // B),
                  'value_counts': 'every transition once per epoch (value = n_epochs x T x N / step time; '
                                  'unique_transitions_per_sec = value / n_epochs)',
@@ -418,6 +433,21 @@ def bench_ppo(args, rank, world, dev):
   }
   res.update(extra)
   cols = keep['cols']
+  if bx:
+    # the same step with the exact-f32 products (the parity mode), timed the same way on every rank: both variants in the line
+    main_ctl = ctl
+    ctl, _ = make_ppo_controller(args, dev, products='f32')
+    dt_x = timed_steps(step, steps, warmup, world)
+    e0, e1, e2 = phase['ev']
+    res['variants'] = {
+        'bf16x6': {'value': round(value, 1), 'ms_per_step': round(dt / steps * 1e3, 3), 'ms_learn_epochs': round(ms_learn, 3),
+                   'dtype': DTYPE_NOTE['bf16x6']},
+        'exact_f32': {'value': round(learned / dt_x, 1), 'ms_per_step': round(dt_x / steps * 1e3, 3),
+                      'ms_learn_epochs': round(e1.elapsed_time(e2), 3), 'dtype': 'f32',
+                      'note': 'products="f32": k_ac_learn_pair on v_mfma_f32_32x32x2_f32, the parity mode (bit-identical to the '
+                              'layer path / multi-rank sequence, tests/test_gpu_learn.py)'}}
+    exact_ctl, ctl = ctl, main_ctl
+    cols = prepare()
   if rank == 0 and world == 1 and not args.no_sweep:
     res['minibatch_sweep'] = minibatch_sweep(args, ctl, cols, n, ms_return, learn_slice, B, dt / steps * 1e3)
     if args.hidden != '256':
@@ -432,7 +462,11 @@ def bench_ppo(args, rank, world, dev):
                                                       'compute_return time taken from the headline run'))
             for Bm in (64, 32)]
   if ctl._fused is not None:
-    res['learn_kernel'] = learn_kernel_roofline(args, ctl, cols, min(B, n))
+    if bx:
+      res['learn_kernel'] = learn_kernel_roofline(args, exact_ctl, cols, min(B, n))
+      res['learn_kernel_bf16x6'] = learn_kernel_roofline(args, ctl, cols, min(B, n))
+    else:
+      res['learn_kernel'] = learn_kernel_roofline(args, ctl, cols, min(B, n))
   return res, dict(T=T, hidden=hidden, B=B, epochs=args.epochs)
 
 
@@ -533,6 +567,22 @@ def learn_kernel_roofline(args, ctl, cols, Bk):
       flops += (4 if i == 0 else 6) * m.in_features * m.out_features
   flops *= Bk
   tf = flops / (us_l * 1e-6) / 1e12
+  if f.bx6_takes(Bk):
+    # the square products' FLOPs are issued six times over on the bf16 pipe; the rest stays on the f32 pipe / VALU
+    sq = sum(6 * m.in_features * m.out_features for lin in (f.critic_lin, f.actor_lin) for m in lin[1:-1]) * Bk
+    issued = 6 * sq / (us_l * 1e-6) / 1e12
+    return {'kernel': 'k_ac_learn_pair_bx+k_learn_reduce', 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': BF16_MFMA_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(issued / BF16_MFMA_PEAK_TFLOPS, 4), 'issued_bf16': round(issued, 1),
+            'f32_equivalent_vs_f32_mfma_peak': round(tf / F32_MFMA_PEAK_TFLOPS, 4), 'us_per_launch': round(us_l, 2),
+            'us_single_launch_pairs': {'mean': round(sum(singles) / len(singles), 2), 'min': round(min(singles), 2),
+                                       'max': round(max(singles), 2)},
+            'flops_per_launch': int(flops), 'entry': 'learn_kernel_bf16x6',
+            'profile': 'profiles/r03_learn_kernel_bf16x6_kernel_stats.csv',
+            'note': 'the same launch pair with products="bf16x6" over one minibatch of %d: `achieved` = the networks\' own %d FLOP per '
+                    'sample (f32-equivalent work) per second; `issued_bf16` = 6 x the three 64 x 64 products on '
+                    'v_mfma_f32_32x32x16_bf16, `frac` = issued_bf16 / the dense bf16 peak.  The kernel is bound by the SIMD\'s '
+                    'issue of MFMA + VALU together (the operand splits are 4.5 VALU instructions per element and do not overlap '
+                    'the matrix pipe on this part, DESIGN.md section 4.5)' % (Bk, flops // Bk)}
   out = {'kernel': 'k_ac_learn+k_learn_reduce', 'bound': 'mfma', 'achieved': round(tf, 1),
          'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
          'us_per_launch': round(us_l, 2), 'us_single_launch_pairs': {'mean': round(sum(singles) / len(singles), 2),
@@ -841,8 +891,8 @@ def run_only(args, dev):
     _, kind, B = e.split('_')
     atari = kind == 'wide'
     return gather_roofline(dev, args.kernel_iters, 200_000 if atari else 1_000_000, int(B), atari=atari)
-  if e == 'learn_kernel':
-    ctl, _ = make_ppo_controller(args, dev)
+  if e in ('learn_kernel', 'learn_kernel_bf16x6'):
+    ctl, _ = make_ppo_controller(args, dev, products='bf16x6' if e.endswith('bf16x6') else 'f32')
     n = args.minibatch or 1048576
     g = torch.Generator(device=dev).manual_seed(1)
     cols = (torch.randn(n, 3, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g),

@@ -12,7 +12,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ENTRIES=("$@")
 if [ ${#ENTRIES[@]} -eq 0 ]; then
-  ENTRIES=(gae_cold_blocked gae_warm_blocked gae_cold_tn gae_warm_tn gather_wide_1024 gather_wide_256 gather_narrow_65536 gather_narrow_128 learn_kernel learn_epoch learn_epoch_256)
+  ENTRIES=(gae_cold_blocked gae_warm_blocked gae_cold_tn gae_warm_tn gather_wide_1024 gather_wide_256 gather_narrow_65536 gather_narrow_128 learn_kernel learn_kernel_bf16x6 learn_epoch learn_epoch_256)
 fi
 for e in "${ENTRIES[@]}"; do
   d="$OUT/raw_$e"

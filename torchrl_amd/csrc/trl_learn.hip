@@ -1836,6 +1836,22 @@ __device__ __forceinline__ void bx_product(f32x16 (&out)[2], const f32x16 (&bsrc
   }
 }
 
+// layer 0 over a fan-in <= 4 as exactly two k steps, no loop (x rows / W0 columns beyond the fan-in are zero, or a ones
+// row against a zero column): pre-activations.  TR = false: the accumulator layout of fwd_layer0 (lane = sample, W0 the
+// A operand).  TR = true: transposed -- x the A operand, W0 the B operand: lane = feature, register r = sample feat(r, half).
+template <int LDW0, bool TR>
+__device__ __forceinline__ void bx_layer0(f32x16 (&h)[2], const float *sX, const float *sW0, int half, int r32) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int k = 2 * s + half;
+    const float xv = sX[k * LDT + r32];
+    const float w0 = sW0[r32 * LDW0 + k];
+    const float w1 = sW0[(32 + r32) * LDW0 + k];
+    if (TR) { h[0] = MFMA(xv, w0, h[0]); h[1] = MFMA(xv, w1, h[1]); }
+    else { h[0] = MFMA(w0, xv, h[0]); h[1] = MFMA(w1, xv, h[1]); }
+  }
+}
+
 template <int NO>
 __global__ __launch_bounds__(512) void k_ac_learn_pair_bx(LearnArgs P) {
   constexpr int NT = 512, LDW0 = 5;
@@ -1902,7 +1918,6 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair_bx(LearnArgs P) {
   const int64_t nstrips = (B + 31) >> 5;
   const int64_t sstride = (int64_t)gridDim.x * 4;
   int64_t strip = (int64_t)blockIdx.x * 4 + pair;
-  const int ksteps0 = (K0 + 1) >> 1;
 
   float vdb0 = 0.f;                                                  // B
   f32x4 dw0m = {0.f, 0.f, 0.f, 0.f};                                 // B: dW0[4 (lane / 4) + i][lane % 4] in element i
@@ -2010,7 +2025,9 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair_bx(LearnArgs P) {
 
       f32x16 h1[2], h2[2];
       float out[NO];
-      fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
+      load_feat_vec(h1, sB, half);
+      bx_layer0<LDW0, false>(h1, sX, sW0, half, r32);
+      relu2(h1);
       load_feat_vec(h2, sB + 64, half);
       bx_product(h2, h1, sW1p, lane);
       relu2(h2);
@@ -2096,14 +2113,7 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair_bx(LearnArgs P) {
         f32x16 xt[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { xt[0][r] = bias0; xt[1][r] = bias1; }
-        for (int s = 0; s < ksteps0; ++s) {
-          const int k = 2 * s + half;
-          const float xv = sX[k * LDT + r32];
-          const float w0 = sW0[r32 * LDW0 + k];
-          const float w1 = sW0[(32 + r32) * LDW0 + k];
-          xt[0] = MFMA(xv, w0, xt[0]);
-          xt[1] = MFMA(xv, w1, xt[1]);
-        }
+        bx_layer0<LDW0, true>(xt, sX, sW0, half, r32);
         relu2(xt);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -2153,8 +2163,9 @@ __global__ __launch_bounds__(512) void k_ac_learn_pair_bx(LearnArgs P) {
         for (int r = 0; r < 16; ++r) t[kb][r] = 0.f;
       bx_product(t, gB, sW1Tp, lane);
       {
-        f32x16 hm[2];
-        fwd_layer0<LDW0>(hm, sX, sW0, sB, ksteps0, half, r32);
+        f32x16 hm[2];      // (pre-activations: relu(z) > 0 is z > 0)
+        load_feat_vec(hm, sB, half);
+        bx_layer0<LDW0, false>(hm, sX, sW0, half, r32);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
