@@ -1,5 +1,5 @@
 """Time PPOController.learn_epoch (one persistent launch over K minibatches) against K learn() calls.
-  python tools/epoch_time.py [hidden] [minibatch] [K]"""
+  python tools/epoch_time.py [hidden] [minibatch] [K] [obs] [actions]"""
 import sys
 import time
 
@@ -11,13 +11,15 @@ from torchrl_amd.contrib.controllers import PPOController  # noqa: E402
 hidden = tuple(int(h) for h in (sys.argv[1] if len(sys.argv) > 1 else '64,64').split(','))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+OBS = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+ACT = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-ctl = PPOController(3, 1, lr=3e-4, alpha=0.5, beta=1e-3, clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden)
+ctl = PPOController(OBS, ACT, lr=3e-4, alpha=0.5, beta=1e-3, clip_ratio=0.2, max_grad_norm=1.0, device=dev, hidden=hidden)
 n = B * K
 g = torch.Generator(device=dev).manual_seed(1)
-cols = [torch.randn(n, 3, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g), None, None, None,
-        torch.randn(n, 1, device=dev, generator=g), torch.randn(n, 1, device=dev, generator=g) - 1.0,
+cols = [torch.randn(n, OBS, device=dev, generator=g), torch.randn(n, ACT, device=dev, generator=g), None, None, None,
+        torch.randn(n, 1, device=dev, generator=g), torch.randn(n, ACT, device=dev, generator=g) - 1.0,
         torch.randn(n, 1, device=dev, generator=g)]
 for _ in range(2):
   ctl.learn_epoch(cols, B, 1)

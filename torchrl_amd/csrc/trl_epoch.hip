@@ -30,6 +30,8 @@
 // consecutive learn() calls, the oracle's torch-CPU loop, the reference's golden two-step fixture).
 #include <string.h>
 
+#include <type_traits>
+
 #include "trl_common.h"
 
 namespace {
@@ -478,7 +480,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   __syncthreads();
 
   // lane = feature pass: this wave's block of 64 features and its share of the tile's samples
-  const int gp_nb = w / L.wpb, gp_sr = w % L.wpb, gp_ns = S / L.wpb;
+  const int gp_nb = w / L.wpb, gp_sr = w % L.wpb;      // (the wave takes S / wpb samples of its block)
   const int gp_n = gp_nb * 64 + lane;
   const bool gp_on = gp_nb < L.NB && gp_n < HL;
   // forward tiles of the last hidden layer: this wave's sample tile and slot of partial dot products
@@ -517,34 +519,72 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       STAMP(0);
       // ---- layer 0: h1[s][n] = relu(x'[s] . W0'[n]) as C[s][n] tiles (lane: 4 consecutive samples of feature n0 + i).
       // One hidden layer: the last layer's dot products ride in the epilogue (16-lane row sums), partials per slot.
+      // A wave's tiles w + NW u share the sample tile; they are computed NTW at a time as straight-line code (every
+      // operand read issued ahead of the first MFMA; a tile is one to four dependent instructions long, so a loop over
+      // tiles waits out each tile's LDS round trip in turn).  A slot beyond the layer repeats tile w & 3 -- the same
+      // values stored to the same place -- with zero last-layer weights.
       {
         const int ntl = 4 * (H1 / 16);
         float pr[O][4];
 #pragma unroll
         for (int o = 0; o < O; ++o) pr[o][0] = pr[o][1] = pr[o][2] = pr[o][3] = 0.f;
-        for (int t0 = w; t0 < ntl; t0 += NW) {
-          const int n0 = (t0 >> 2) * 16;      // (t0 & 3 == w & 3: the wave's sample tile)
-          float wl[O];
+        auto tiles = [&](auto ntw_c, int u0) {      // the wave's tiles w + NW (u0 + u), u < NTW
+          constexpr int NTW = decltype(ntw_c)::value;
+          int n0[NTW];
+          float wl[NTW][O];
+          v4f c[NTW];
 #pragma unroll
-          for (int o = 0; o < O; ++o) wl[o] = D3 ? 0.f : vpp[o * HL + n0 + i];
-          v4f c = {0, 0, 0, 0};
-          if (d0 < 4) {      // fan-in + bias fit one MFMA: k = q
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(X[(f_s0 + i) * LDK + q], w0p[(n0 + i) * LDK + q], c, 0, 0, 0);
-          } else {
-            c = mma<LDK, LDK>(X + f_s0 * LDK, w0p + n0 * LDK, KP, c, i, q);
+          for (int u = 0; u < NTW; ++u) {
+            const int t0 = w + NW * (u0 + u);
+            const bool ok = t0 < ntl;
+            n0[u] = ((ok ? t0 : (w & 3)) >> 2) * 16;
+#pragma unroll
+            for (int o = 0; o < O; ++o) wl[u][o] = (!D3 && ok) ? vpp[o * HL + n0[u] + i] : 0.f;
+            c[u] = (v4f){0, 0, 0, 0};
           }
-          c = relu4(c);
-          *(v4f *)(h1t + (n0 + i) * LS + f_s0 + 4 * q) = c;
-          if (D3) {
-            float *hp = h1 + (f_s0 + 4 * q) * LS + n0 + i;
-            hp[0] = c.x; hp[LS] = c.y; hp[2 * LS] = c.z; hp[3 * LS] = c.w;
-          } else {
+          if (d0 < 4) {      // fan-in + bias fit one MFMA: k = q
+            const float xq = X[(f_s0 + i) * LDK + q];
+            float wq[NTW];
 #pragma unroll
-            for (int o = 0; o < O; ++o) {
-              pr[o][0] = __builtin_fmaf(wl[o], c.x, pr[o][0]); pr[o][1] = __builtin_fmaf(wl[o], c.y, pr[o][1]);
-              pr[o][2] = __builtin_fmaf(wl[o], c.z, pr[o][2]); pr[o][3] = __builtin_fmaf(wl[o], c.w, pr[o][3]);
+            for (int u = 0; u < NTW; ++u) wq[u] = w0p[(n0[u] + i) * LDK + q];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq, wq[u], c[u], 0, 0, 0);
+          } else {
+            const v4f xa = *(const v4f *)(X + (f_s0 + i) * LDK + 4 * q);
+            v4f wb[NTW];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) wb[u] = *(const v4f *)(w0p + (n0[u] + i) * LDK + 4 * q);
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb[u].x, c[u], 0, 0, 0);
+              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb[u].y, c[u], 0, 0, 0);
+              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb[u].z, c[u], 0, 0, 0);
+              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb[u].w, c[u], 0, 0, 0);
             }
           }
+#pragma unroll
+          for (int u = 0; u < NTW; ++u) {
+            const v4f cu = relu4(c[u]);
+            *(v4f *)(h1t + (n0[u] + i) * LS + f_s0 + 4 * q) = cu;
+            if (D3) {
+              float *hp = h1 + (f_s0 + 4 * q) * LS + n0[u] + i;
+              hp[0] = cu.x; hp[LS] = cu.y; hp[2 * LS] = cu.z; hp[3 * LS] = cu.w;
+            } else {
+#pragma unroll
+              for (int o = 0; o < O; ++o) {
+                pr[o][0] = __builtin_fmaf(wl[u][o], cu.x, pr[o][0]); pr[o][1] = __builtin_fmaf(wl[u][o], cu.y, pr[o][1]);
+                pr[o][2] = __builtin_fmaf(wl[u][o], cu.z, pr[o][2]); pr[o][3] = __builtin_fmaf(wl[u][o], cu.w, pr[o][3]);
+              }
+            }
+          }
+        };
+        // (two hidden layers are at most 64 wide: two tiles a wave; one wide layer: four at a time -- eight would hold the
+        // registers of a second kernel)
+        if (D3 || ntl <= 2 * NW) {
+          tiles(std::integral_constant<int, 2>(), 0);
+        } else {
+          constexpr int CH = O <= 2 ? 4 : 2;      // (three or four outputs: their partial dots take the registers)
+          for (int u0 = 0; w + NW * u0 < ntl; u0 += CH) tiles(std::integral_constant<int, CH>(), u0);
         }
         if (!D3 && w < ntl) {
 #pragma unroll
@@ -640,25 +680,43 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         float wl_n[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) wl_n[o] = vpp[o * HL + gp_n];
-#pragma unroll 2
-        for (int s = gp_sr * gp_ns; s < (gp_sr + 1) * gp_ns; s += 4) {
-          const v4f h = *(const v4f *)(hlt + gp_n * LS + s);
-          v4f g = {0, 0, 0, 0};
+        // the wave's gp_ns = 64 / wpb samples, four at a time, as straight-line code: every read ahead of the first store
+        // (the gradient overwrites h in place, which keeps a loop's reads behind the previous iteration's store)
+        auto pass = [&](auto nit_c, int s0) {
+          constexpr int NIT = decltype(nit_c)::value;
+          v4f h[NIT], go[NIT][O];
 #pragma unroll
-          for (int o = 0; o < O; ++o) {
-            const v4f go = *(const v4f *)(gout + o * LS + s);
-            dwl[o] = __builtin_fmaf(go.x, h.x, dwl[o]); dwl[o] = __builtin_fmaf(go.y, h.y, dwl[o]);
-            dwl[o] = __builtin_fmaf(go.z, h.z, dwl[o]); dwl[o] = __builtin_fmaf(go.w, h.w, dwl[o]);
-            g.x = __builtin_fmaf(go.x, wl_n[o], g.x); g.y = __builtin_fmaf(go.y, wl_n[o], g.y);
-            g.z = __builtin_fmaf(go.z, wl_n[o], g.z); g.w = __builtin_fmaf(go.w, wl_n[o], g.w);
+          for (int j = 0; j < NIT; ++j) {
+            h[j] = *(const v4f *)(hlt + gp_n * LS + s0 + 4 * j);
+#pragma unroll
+            for (int o = 0; o < O; ++o) go[j][o] = *(const v4f *)(gout + o * LS + s0 + 4 * j);
           }
-          g = mask4(g, h);
-          *(v4f *)(hlt + gp_n * LS + s) = g;
-          if (D3) {
-            db1 += (g.x + g.y) + (g.z + g.w);
-            float *gp = g2 + s * LS + gp_n;
-            gp[0] = g.x; gp[LS] = g.y; gp[2 * LS] = g.z; gp[3 * LS] = g.w;
+#pragma unroll
+          for (int j = 0; j < NIT; ++j) {
+            v4f g = {0, 0, 0, 0};
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+              dwl[o] = __builtin_fmaf(go[j][o].x, h[j].x, dwl[o]); dwl[o] = __builtin_fmaf(go[j][o].y, h[j].y, dwl[o]);
+              dwl[o] = __builtin_fmaf(go[j][o].z, h[j].z, dwl[o]); dwl[o] = __builtin_fmaf(go[j][o].w, h[j].w, dwl[o]);
+              g.x = __builtin_fmaf(go[j][o].x, wl_n[o], g.x); g.y = __builtin_fmaf(go[j][o].y, wl_n[o], g.y);
+              g.z = __builtin_fmaf(go[j][o].z, wl_n[o], g.z); g.w = __builtin_fmaf(go[j][o].w, wl_n[o], g.w);
+            }
+            g = mask4(g, h[j]);
+            const int s = s0 + 4 * j;
+            *(v4f *)(hlt + gp_n * LS + s) = g;
+            if (D3) {
+              db1 += (g.x + g.y) + (g.z + g.w);
+              float *gp = g2 + s * LS + gp_n;
+              gp[0] = g.x; gp[LS] = g.y; gp[2 * LS] = g.z; gp[3 * LS] = g.w;
+            }
           }
+        };
+        const int ns = S / L.wpb;      // 8 (one block of 64 features), 16 or 32 samples
+        if (D3 || ns == 8) {
+          pass(std::integral_constant<int, 2>(), gp_sr * ns);
+        } else {
+          constexpr int CH = O <= 2 ? 4 : 2;
+          for (int c0 = 0; c0 < ns; c0 += 4 * CH) pass(std::integral_constant<int, CH>(), gp_sr * ns + c0);
         }
       }
       __syncthreads();
