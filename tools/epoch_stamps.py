@@ -26,8 +26,8 @@ lib = _lib.lib()
 lib.trl_tune_epoch_stamps.argtypes = [C.c_void_p]
 assert lib.trl_tune_epoch_stamps(out) == 0
 names = ['layer 0 (+ barrier)', 'layer 1 + last-layer dots (+ barrier)', 'loss, wave 0 (+ barrier)', 'lane = feature pass (+ barrier)', 'dW1',
-         'g1 (+ barrier)', "dW0'", 'input swap', 'gradient / partial / loss-sum flush (+ barrier)', 'small-vector Adam', 'layer-0 Adam',
-         'W1 tile Adam', 'barrier']
+         'g1 (+ barrier)', "dW0'", 'input swap', 'gradient / partial / loss-sum flush (+ barrier)', '-', '-',
+         'clip + Adam: small vectors, layer 0, W1 tiles (one stream)', 'barrier']
 for role in range(2):
   st = [[out[(role * 8 + w) * 16 + j] for j in range(14)] for w in range(8)]
   print('critic' if role == 0 else 'actor', 'total cycles (s_memtime ticks), wave 0:', st[0][13] - st[0][0])

@@ -856,16 +856,35 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
     const AdamV sc = {P.w1, P.beta2, P.c2, P.eps, P.clip, uni(step_k.x), uni(step_k.z), uni(step_k.y)};
     const bool last = k + 1 == K;
-    // the small vectors, dealt from the far end of the workgroup (layer 0's groups start at thread 0): thread NT - 1 - T
-    // takes group T of four consecutive elements of [wL | b1] -- its gradient the partial planes of the lane = feature
-    // pass added in plane order -- or, behind the groups, ONE element of [bL | log_std]; one adam4 either way
-    {
-      const int T = NT - 1 - tid, nvec = L.o_bl >> 2;
-      if (T < nvec + (L.NV - L.o_bl)) {
-        const bool vec = T < nvec;
-        const int e0 = vec ? 4 * T : L.o_bl + (T - nvec);
-        v4f g4 = {0, 0, 0, 0}, p4 = {0, 0, 0, 0}, m4 = {0, 0, 0, 0}, v4 = {0, 0, 0, 0};
-        if (vec) {
+    STAMP(10);
+    STAMP(11);
+    // The update of everything this wave owns as ONE straight-line stream per combination of what it owns, so that the
+    // adam4s -- each a dependent chain of ~50 instructions (square root, two divisions) -- overlap one another instead
+    // of running one after the other behind wave-uniform branches:
+    //   * the small vectors, dealt from the far end of the workgroup (layer 0's groups start at thread 0): thread
+    //     NT - 1 - T takes group T of four consecutive elements of [wL | b1] -- its gradient the partial planes of the
+    //     lane = feature pass added in plane order -- or, behind the groups, ONE element of [bL | log_std];
+    //   * layer 0: the thread's groups of four (the clipped gradient goes back to gw0: the last update's is written out
+    //     after the loop);
+    //   * W1's accumulator tiles (two hidden layers), merged into the stream when the wave owns both of its slots.
+    const int T = NT - 1 - tid, nvec = L.o_bl >> 2, nsmall = nvec + (L.NV - L.o_bl);
+    auto tile_update = [&](int u) {
+      float *wp = w1 + (r1[u] + 4 * q) * LS + c1[u] + i;
+      v4f p4 = {wp[0], wp[LS], wp[2 * LS], wp[3 * LS]};
+      adam4(p4, acc1[u], m1[u], v1[u], sc);
+      wp[0] = p4.x; wp[LS] = p4.y; wp[2 * LS] = p4.z; wp[3 * LS] = p4.w;
+      *(v4f *)(w1t + (c1[u] + i) * LS + r1[u] + 4 * q) = p4;
+      if (!last) acc1[u] = (v4f){0, 0, 0, 0};      // (the last update's clipped gradient is written out after the loop)
+    };
+    auto update = [&](auto sv_c, auto nl0_c, auto t2_c) {
+      constexpr bool SV = decltype(sv_c)::value, T2 = decltype(t2_c)::value;
+      constexpr int NL0 = decltype(nl0_c)::value;
+      // ---- reads
+      const bool sv_on = SV && T < nsmall, vec = T < nvec;
+      const int e0 = vec ? 4 * T : L.o_bl + (T - nvec);
+      v4f sg = {0, 0, 0, 0}, sp = {0, 0, 0, 0}, sm = {0, 0, 0, 0}, svv = {0, 0, 0, 0};
+      if (SV) {
+        if (sv_on && vec) {
           int plane = O, n = e0 - L.o_b1;      // (b1's plane, two hidden layers)
           if (e0 < L.o_b1) {
             plane = 0; n = e0;
@@ -875,63 +894,106 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           }
           v4f pl[NW];
 #pragma unroll
-          for (int sr = 0; sr < NW; ++sr)
-          {      // (always a valid address: planes beyond the layout's count read plane 0 and count as zeros)
+          for (int sr = 0; sr < NW; ++sr) {      // (always a valid address: planes beyond the layout's count read plane 0 and count as zeros)
             const v4f x = *(const v4f *)(part + ((sr < L.wpb ? sr : 0) * L.PO + plane) * L.HLP + n);
             pl[sr] = sr < L.wpb ? x : (v4f){0, 0, 0, 0};
           }
 #pragma unroll
-          for (int sr = 0; sr < NW; ++sr) g4 = g4 + pl[sr];
-          p4 = *(const v4f *)(vpp + e0); m4 = *(const v4f *)(vpm + e0); v4 = *(const v4f *)(vpv + e0);
-        } else {
-          g4.x = tailg[T - nvec]; p4.x = vpp[e0]; m4.x = vpm[e0]; v4.x = vpv[e0];
-        }
-        adam4(p4, g4, m4, v4, sc);
-        if (vec) {
-          *(v4f *)(vpp + e0) = p4; *(v4f *)(vpm + e0) = m4; *(v4f *)(vpv + e0) = v4;
-          if (last) {      // the gradients the last learn() leaves behind (after clip_grad_value_)
-            float *gd = P.grad + vp_global(e0);
-            gd[0] = g4.x; gd[1] = g4.y; gd[2] = g4.z; gd[3] = g4.w;
-          }
-        } else {
-          vpp[e0] = p4.x; vpm[e0] = m4.x; vpv[e0] = v4.x;
-          if (last) P.grad[vp_global(e0)] = g4.x;
+          for (int sr = 0; sr < NW; ++sr) sg = sg + pl[sr];
+          sp = *(const v4f *)(vpp + e0); sm = *(const v4f *)(vpm + e0); svv = *(const v4f *)(vpv + e0);
+        } else if (sv_on) {
+          sg.x = tailg[T - nvec]; sp.x = vpp[e0]; sm.x = vpm[e0]; svv.x = vpv[e0];
         }
       }
-    }
-    STAMP(10);
-    // layer 0: the thread's groups (the clipped gradient goes back to gw0: the last update's is written out after the loop)
+      int at0[NL0 > 0 ? NL0 : 1][4];
+      v4f lp[NL0 > 0 ? NL0 : 1], lg[NL0 > 0 ? NL0 : 1];
+      bool l_on[NL0 > 0 ? NL0 : 1];
 #pragma unroll
-    for (int u = 0; u < G0; ++u) {
-      if (4 * (tid + u * NT) < n0v) {
-        int at0[4];
-        group_at(u, at0);
+      for (int u = 0; u < NL0; ++u) {
+        l_on[u] = 4 * (tid + u * NT) < n0v;
+        group_at(u, at0[u]);
         float pp[4], gg[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int at = at0[r] >= 0 ? at0[r] : at0[0];
+          const int at = at0[u][r] >= 0 ? at0[u][r] : (at0[u][0] >= 0 ? at0[u][0] : 0);      // (always a valid address)
           pp[r] = w0p[at]; gg[r] = gw0[at];
         }
-        v4f p4 = {pp[0], pp[1], pp[2], pp[3]}, g4 = {gg[0], gg[1], gg[2], gg[3]};
-        adam4(p4, g4, m0[u], v0[u], sc);
-        const float po[4] = {p4.x, p4.y, p4.z, p4.w}, go[4] = {g4.x, g4.y, g4.z, g4.w};
+        lp[u] = (v4f){pp[0], pp[1], pp[2], pp[3]}; lg[u] = (v4f){gg[0], gg[1], gg[2], gg[3]};
+      }
+      v4f tp[T1];
+      if (T2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (at0[r] >= 0) { w0p[at0[r]] = po[r]; gw0[at0[r]] = go[r]; }
+        for (int u = 0; u < T1; ++u) {
+          const float *wp = w1 + (r1[u] + 4 * q) * LS + c1[u] + i;
+          tp[u] = (v4f){wp[0], wp[LS], wp[2 * LS], wp[3 * LS]};
         }
       }
-    }
-    STAMP(11);
+      // ---- the arithmetic, one block
+      if (SV) adam4(sp, sg, sm, svv, sc);
 #pragma unroll
-    for (int u = 0; u < T1; ++u) {
-      if (own1[u]) {
-        float *wp = w1 + (r1[u] + 4 * q) * LS + c1[u] + i;
-        v4f p4 = {wp[0], wp[LS], wp[2 * LS], wp[3 * LS]};
-        adam4(p4, acc1[u], m1[u], v1[u], sc);
-        wp[0] = p4.x; wp[LS] = p4.y; wp[2 * LS] = p4.z; wp[3 * LS] = p4.w;
-        *(v4f *)(w1t + (c1[u] + i) * LS + r1[u] + 4 * q) = p4;
-        if (!last) acc1[u] = (v4f){0, 0, 0, 0};      // (the last update's clipped gradient is written out after the loop)
+      for (int u = 0; u < NL0; ++u) adam4(lp[u], lg[u], m0[u], v0[u], sc);
+      if (T2) {
+#pragma unroll
+        for (int u = 0; u < T1; ++u) adam4(tp[u], acc1[u], m1[u], v1[u], sc);
       }
+      // ---- writes
+      if (SV && sv_on) {
+        if (vec) {
+          *(v4f *)(vpp + e0) = sp; *(v4f *)(vpm + e0) = sm; *(v4f *)(vpv + e0) = svv;
+          if (last) {      // the gradients the last learn() leaves behind (after clip_grad_value_)
+            float *gd = P.grad + vp_global(e0);
+            gd[0] = sg.x; gd[1] = sg.y; gd[2] = sg.z; gd[3] = sg.w;
+          }
+        } else {
+          vpp[e0] = sp.x; vpm[e0] = sm.x; vpv[e0] = svv.x;
+          if (last) P.grad[vp_global(e0)] = sg.x;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NL0; ++u) {
+        if (l_on[u]) {
+          const float po[4] = {lp[u].x, lp[u].y, lp[u].z, lp[u].w}, go[4] = {lg[u].x, lg[u].y, lg[u].z, lg[u].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (at0[u][r] >= 0) { w0p[at0[u][r]] = po[r]; gw0[at0[u][r]] = go[r]; }
+          }
+        }
+      }
+      if (T2) {
+#pragma unroll
+        for (int u = 0; u < T1; ++u) {
+          float *wp = w1 + (r1[u] + 4 * q) * LS + c1[u] + i;
+          wp[0] = tp[u].x; wp[LS] = tp[u].y; wp[2 * LS] = tp[u].z; wp[3 * LS] = tp[u].w;
+          *(v4f *)(w1t + (c1[u] + i) * LS + r1[u] + 4 * q) = tp[u];
+          if (!last) acc1[u] = (v4f){0, 0, 0, 0};
+        }
+      } else if (D3) {
+#pragma unroll
+        for (int u = 0; u < T1; ++u)
+          if (own1[u]) tile_update(u);
+      }
+    };
+    {
+      // what this WAVE owns (wave-uniform: its last lane has the smallest T, its first lane the smallest group number)
+      const bool sv_wave = NT - 64 * (w + 1) < nsmall;
+      const int nl0_wave = 4 * (64 * w) < n0v ? ((G0 > 1 && 4 * (64 * w + NT) < n0v) ? 2 : 1) : 0;
+      const bool t2 = D3 && T1 == 2 && own1[0] && own1[T1 - 1];
+      using std::integral_constant;
+#define TRL_UPD(sv, nl0, tt) update(integral_constant<bool, sv>(), integral_constant<int, nl0>(), integral_constant<bool, tt>())
+      if (D3) {      // (at most 64 wide: layer 0 is at most 256 groups, the small vectors at most 88: never in one wave)
+        if (t2) {
+          if (sv_wave) TRL_UPD(true, 0, D3); else if (nl0_wave) TRL_UPD(false, 1, D3); else TRL_UPD(false, 0, D3);
+        } else {
+          if (sv_wave) TRL_UPD(true, 0, false); else if (nl0_wave) TRL_UPD(false, 1, false); else TRL_UPD(false, 0, false);
+        }
+      } else {
+        if (sv_wave) {
+          if (nl0_wave == 2) TRL_UPD(true, 2, false); else if (nl0_wave == 1) TRL_UPD(true, 1, false); else TRL_UPD(true, 0, false);
+        } else {
+          if (nl0_wave == 2) TRL_UPD(false, 2, false); else if (nl0_wave == 1) TRL_UPD(false, 1, false);
+        }
+      }
+#undef TRL_UPD
     }
     STAMP(12);
     __syncthreads();
