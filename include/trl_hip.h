@@ -401,6 +401,12 @@ int trl_a2c_learn_fused_bx6(const trl_mlp_desc *critic, const trl_mlp_desc *acto
                             double alpha, double beta, float *losses_out, float *const *critic_grads,
                             float *const *actor_grads, const trl_adam_args *adam, void *ws, void *stream);
 
+/* trl_ppo_forward_fused with layer 1's product as in the two entry points above (same staging, split and accumulation
+ * order: a row's value / mean / log-prob is the bit pattern THEIR forward computes for it).  Same shapes as they take. */
+int trl_ppo_forward_fused_bx6(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                              const float *obs, const float *action, int64_t B, int32_t A, float *value,
+                              float *mean, float *logp, void *stream);
+
 /* Test surface of the two entry points above: y[64][n] = w[64][64] x[64][n] (row-major device arrays) computed with
  * exactly their operand split, partial products and accumulation order, so that the product's error can be bounded
  * against float64 on adversarial inputs without a network around it.  No counterpart in the reference. */

@@ -160,3 +160,39 @@ def test_bx6_a2c_and_shapes_outside_the_variant():
   assert not small._fused.bx6_takes(4096)                                    # small batches: the exact kernels
   with pytest.raises(ValueError):
     PPOController(3, 1, device=DEV, hidden=(64, 64), products='fp8')
+
+
+@pytest.mark.parametrize('obs_size,A,B', [(3, 1, 40001), (4, 2, 33000)])
+def test_bx6_forward_kernel_matches_torch_and_the_learner_forward(obs_size, A, B):
+  """trl_ppo_forward_fused_bx6 (compute_return's value / log-prob pass with layer 1 on the bf16 MFMA): against the torch
+  modules at the exact forward's tolerances, and -- same staging, split and accumulation order -- the same BITS as the
+  forward inside trl_ppo_learn_fused_bx6: with its values as the returns the learner's critic loss and critic gradients are
+  exactly zero, with its log-probs as the old ones no ratio leaves [1 - 1e-30, 1 + 1e-30]."""
+  torch.manual_seed(B + obs_size)
+  ctl = PPOController(obs_size, A, device=DEV, hidden=(64, 64), products='bf16x6')
+  with torch.no_grad():
+    ctl.ac_net.log_std.add_(torch.linspace(-0.4, 0.3, A, device=DEV).view(1, A))
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  obs, act, _, adv, _ = _batch(obs_size, A, B, 3)
+  with torch.no_grad():
+    ev, em = ref.critic(obs), ref.actor(obs)
+    elp = torch.distributions.Normal(em, ref.log_std.exp().expand_as(em)).log_prob(act)
+  obs, act, adv = obs.to(DEV), act.to(DEV), adv.to(DEV)
+  assert ctl._fused.bx6_takes(B)
+  value, mean, logp = ctl._fused.forward(obs, act)
+  torch.testing.assert_close(value.cpu(), ev.view(-1), rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(mean.cpu(), em, rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(logp.cpu(), elp, rtol=1e-5, atol=1e-5)
+  ret = value.view(B, 1).clone()
+  res = []
+  for clip in (0.2, 1e-30):
+    ctl._fused(obs, act, ret, logp, adv, clip, 0.5, 1e-3)
+    res.append(ctl._flat.grad.clone())
+  losses = ctl._fused(obs, act, ret, logp, adv, 0.2, 0.5, 1e-3).cpu()
+  assert float(losses[1]) == 0.0
+  off = 0
+  for name, p_ in ctl.ac_net.named_parameters():
+    if name.startswith('critic'):
+      assert not res[0][off:off + p_.numel()].any(), name
+    off += p_.numel()
+  assert torch.equal(res[0], res[1])

@@ -120,6 +120,8 @@ PROTOTYPES = {
                                           C.POINTER(AdamArgs), _vp, _vp]),
     'trl_a2c_learn_fused_bx6': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _i64, _i32, _f64,
                                           _f64, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(AdamArgs), _vp, _vp]),
+    'trl_ppo_forward_fused_bx6': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp,
+                                            _vp]),
     'trl_bx6_product_probe': (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     'trl_ppo_learn_epoch_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'trl_ppo_learn_epoch_supported': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _i32]),

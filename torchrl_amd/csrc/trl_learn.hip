@@ -1779,11 +1779,12 @@ __device__ __forceinline__ void bx_split8(const f32x16 &v, int s, u32x4 (&part)[
 // W1's parts into LDS in operand order.  sW1p [3][nb][ks][64][4 dwords]: lane (n = nb 32 + r32, half), step ks = (kb, s'):
 // W1[n][kb 32 + feat(8 s' + j, half)], j = 0 .. 7.  sW1Tp [3][kbo][ks][64][4]: lane (k = kbo 32 + r32, half), step
 // ks = (nb, s'): W1[nb 32 + feat(8 s' + j, half)][k].  Zero beyond the layer's real size.
+template <int NT = 512, bool WITH_T = true>
 __device__ __forceinline__ void bx_stage_w1(const NetArgs &a, unsigned int *sW1p, unsigned int *sW1Tp, int tid) {
   const int H1 = a.dims[1], H2 = a.dims[2];
   constexpr int NPOS = 2 * 4 * 64 * 4;      // dword positions of one part
   const float *w1 = a.w[1];
-  for (int pos = tid; pos < 2 * NPOS; pos += 512) {
+  for (int pos = tid; pos < (WITH_T ? 2 : 1) * NPOS; pos += NT) {
     const bool tr = pos >= NPOS;
     const int q = tr ? pos - NPOS : pos;
     const int d = q & 3, ln = (q >> 2) & 63, ks = (q >> 8) & 3, blk = q >> 10;
@@ -2298,12 +2299,15 @@ struct InferArgs {
 };
 
 // (amdgpu_waves_per_eu(2): a register budget of 256, so that the MFMA results are taken in VGPRs -- see k_ac_learn_wide)
-template <int D, int KB0, int NO, bool XP>     // (hidden layers of at most 64 units; a wider one is k_ac_infer_wide's)
+// BX (two hidden layers): layer 1 on the bf16 MFMA with exactly split operands -- the forward of k_ac_learn_pair_bx, the same
+// staging, split and accumulation order (trl_ppo_forward_fused_bx6)
+template <int D, int KB0, int NO, bool XP, bool BX = false>     // (hidden layers of at most 64 units; a wider one is k_ac_infer_wide's)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ac_infer(InferArgs P) {
   constexpr int LDW0 = 32 * KB0 + 1;
   constexpr int XT = 32 * KB0 * LDT + 4;
+  static_assert(!BX || D == 3, "the bf16x6 product is layer 1's");
   __shared__ __align__(16) float sW0[64 * LDW0];
-  __shared__ __align__(16) float sW1[D == 3 ? 64 * LDW : 4];
+  __shared__ __align__(16) float sW1[D == 3 ? (BX ? 3 * 2 * 4 * 64 * 4 : 64 * LDW) : 4];
   __shared__ __align__(16) float sWL[NO * 64];
   __shared__ __align__(16) float sB[64 + 64 + 4];
   __shared__ __align__(16) float sT[4 * XT];
@@ -2313,7 +2317,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const int K0 = a.dims[0];
   const int64_t B = P.B;
   const int A = P.A;
-  stage_weights<D, LDW0, NO, false>(a, sW0, sW1, nullptr, sWL, sB, tid);
+  if (BX) {      // (stage_weights<2> leaves out W1 and takes layer 1 for the last one: redo the last layer and the biases)
+    stage_weights<2, LDW0, NO, false>(a, sW0, nullptr, nullptr, sWL, sB, tid);
+    __syncthreads();
+    const int HL = a.dims[2], NOr = a.dims[3];
+    for (int e = tid; e < NO * 64; e += 256) {
+      const int n = e >> 6, k = e & 63;
+      sWL[e] = (n < NOr && k < HL) ? a.w[2][n * HL + k] : 0.f;
+    }
+    for (int e = tid; e < 64 + 4; e += 256) {
+      if (e < 64) sB[64 + e] = e < HL ? a.b[1][e] : 0.f;
+      else sB[128 + e - 64] = e - 64 < NOr ? a.b[2][e - 64] : 0.f;
+    }
+    bx_stage_w1<256, false>(a, (unsigned int *)sW1, nullptr, tid);
+  } else {
+    stage_weights<D, LDW0, NO, false>(a, sW0, sW1, nullptr, sWL, sB, tid);
+  }
   float *sX = sT + wave * XT;
   for (int e = lane; e < XT; e += 64) sX[e] = 0.f;
   __syncthreads();
@@ -2397,7 +2416,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     f32x16 h1[2], h2[2];
     float out[NO];
     fwd_layer0<LDW0>(h1, sX, sW0, sB, ksteps0, half, r32);
-    if (D == 3) fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+    if (D == 3 && BX) {
+      load_feat_vec(h2, sB + 64, half);
+      bx_product(h2, h1, (const unsigned int *)sW1, lane);
+      relu2(h2);
+    } else if (D == 3) {
+      fwd_layer1(h2, h1, sW1, sB + 64, half, r32);
+    }
     fwd_last<NO>(out, D == 3 ? h2 : h1, sWL, sB + 128, half);
     if (valid && half == 0) {
       if (net == 0) {
@@ -2886,10 +2911,10 @@ extern "C" int trl_bx6_product_probe(const float *w, const float *x, float *y, i
   return TRL_OK;
 }
 
-extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
-                                     const float *obs, const float *action, int64_t B, int32_t A, float *value,
-                                     float *mean, float *logp, void *stream) {
-  const char *fn = "trl_ppo_forward_fused";
+namespace {
+int forward_fused(const char *fn, bool bx6, const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                  const float *obs, const float *action, int64_t B, int32_t A, float *value, float *mean, float *logp,
+                  void *stream) {
   TRL_REQUIRE(obs, "%s: null obs", fn);
   TRL_REQUIRE(B > 0 && B < (1ll << 36), "%s: B=%lld out of range", fn, (long long)B);
   TRL_REQUIRE(value || mean || logp, "%s: no output requested", fn);
@@ -2934,7 +2959,12 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
     if (kb == 1 && xp) hipLaunchKernelGGL((k_ac_infer<d, kb, no, kb == 1>), grid, block, 0, st, P); \
     else hipLaunchKernelGGL((k_ac_infer<d, kb, no, false>), grid, block, 0, st, P);               \
   }
-  if (wide) {     // wide single hidden layer (fill_net has checked fan-in <= 4): blocks of 64
+  if (bx6) {
+    TRL_REQUIRE(D == 3 && K0 <= 4 && NOv <= 2,
+                "%s: the bf16x6 product exists for two hidden layers <= 64 wide over at most 4 observations and at most 2 actions", fn);
+    if (NOv == 1) hipLaunchKernelGGL((k_ac_infer<3, 1, 1, true, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_ac_infer<3, 1, 2, true, true>), grid, block, 0, st, P);
+  } else if (wide) {     // wide single hidden layer (fill_net has checked fan-in <= 4): blocks of 64
     const int HBv = hmax <= 64 ? 1 : (hmax <= 128 ? 2 : 4), KSv = wide_ks(K0);
 #define TRL_WIDE_CASE(no, hb, ks) \
   if (NOv == no && HBv == hb && KSv == ks) hipLaunchKernelGGL((k_ac_infer_wide<no, hb, ks>), grid, block, 0, st, P);
@@ -2954,4 +2984,17 @@ extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_d
 #undef TRL_INFER_CASE
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
+}
+}  // namespace
+
+extern "C" int trl_ppo_forward_fused(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                     const float *obs, const float *action, int64_t B, int32_t A, float *value,
+                                     float *mean, float *logp, void *stream) {
+  return forward_fused("trl_ppo_forward_fused", false, critic, actor, log_std, obs, action, B, A, value, mean, logp, stream);
+}
+
+extern "C" int trl_ppo_forward_fused_bx6(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                         const float *obs, const float *action, int64_t B, int32_t A, float *value,
+                                         float *mean, float *logp, void *stream) {
+  return forward_fused("trl_ppo_forward_fused_bx6", true, critic, actor, log_std, obs, action, B, A, value, mean, logp, stream);
 }

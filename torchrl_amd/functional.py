@@ -805,8 +805,10 @@ class FusedPpoLearn:
     value = torch.empty(B, dtype=torch.float32, device=dev) if want_value else None
     mean = torch.empty((B, self.A), dtype=torch.float32, device=dev) if want_mean else None
     logp = torch.empty((B, self.A), dtype=torch.float32, device=dev) if action is not None else None
+    lib = _lib.lib()
+    fn = lib.trl_ppo_forward_fused_bx6 if self.bx6_takes(B) else lib.trl_ppo_forward_fused
     with torch.cuda.device(dev):
-      _lib.check(_lib.lib().trl_ppo_forward_fused(
+      _lib.check(fn(
           C.byref(self.descs[0]), C.byref(self.descs[1]), _lib.ptr(self.log_std), obs.data_ptr(), _lib.ptr(action),
           B, self.A, _lib.ptr(value), _lib.ptr(mean), _lib.ptr(logp), _lib.stream_ptr(dev)))
     return value, mean, logp
