@@ -85,6 +85,9 @@ def parse(argv=None):
                   help='off-policy loops: keep the BLAS default kernel picks (default: PyTorch TunableOp chooses per shape)')
   ap.add_argument('--f32-frames', action='store_true',
                   help='dqn_atari: gather the uint8 frames as float32 (the path before the uint8 first layer)')
+  ap.add_argument('--dqn-chain', action='store_true',
+                  help='dqn_atari: layer 1, layer 2, TD loss and input gradients of the uint8 step as ONE launch '
+                       '(trl_offpolicy_set_chain(2)); default: four launches')
   ap.add_argument('--in-place', action='store_true',
                   help='dqn_atari: read the sampled frames in place out of the ring (learn_indexed(in_place=True)) instead of '
                        'gathering a dense batch first; bit-identical results, measured slower')
@@ -408,7 +411,9 @@ def bench_ppo(args, rank, world, dev):
   if N % args.block_envs == 0:
     roof['other_layout'] = gae_roofline(args, dev, T, N, other, with_ceilings=False)
   share_learn = ms_learn / max(ms_return + ms_learn, 1e-9)
-  extra = {'step_time_share': {'learn epochs (k_ac_learn + k_learn_reduce: see learn_kernel, MFMA-bound)': round(share_learn, 3),
+  lk = 'k_ac_learn_pair_bx + k_learn_reduce: see learn_kernel_bf16x6, MFMA + VALU issue-bound' if bx else \
+       'k_ac_learn + k_learn_reduce: see learn_kernel, MFMA-bound'
+  extra = {'step_time_share': {'learn epochs (%s)' % lk: round(share_learn, 3),
                                'compute_return (k_ac_infer x2 + k_gae_pipe: see roofline, HBM-bound)': round(1 - share_learn, 3)},
            'gae_steps_per_sec_kernel': round(n / (roof['us_per_launch'] * 1e-6), 1),
            'gae_steps_per_sec_compute_return': round(n / (ms_return * 1e-3), 1),
@@ -791,6 +796,9 @@ def bench_offpolicy(args, rank, world, dev, atari):
     wl = 'ddpg: %d-row Pendulum-shaped f32 replay per GPU, actor/critic MLP 256x256' % cap
 
   in_place = atari and not args.f32_frames and args.in_place
+  if atari and args.dqn_chain:
+    from torchrl_amd import _lib
+    _lib.lib().trl_offpolicy_set_chain(2)
   if in_place:
     # --in-place: the sampled frames are read where the ring holds them (DQNController.learn_indexed(in_place=True): the
     # gather as the first layer's operand fetch).  Measured slower than the gathered batch, hence opt-in

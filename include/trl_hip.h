@@ -502,7 +502,11 @@ int trl_ddpg_learn_fused(const trl_mlp_desc *actor, const trl_mlp_desc *critic, 
  * bits.  The one-launch form keeps, per (device, stream), 1 KB of device memory and a small ring of pinned host memory
  * for the phase tables, allocated at the first call on that stream and kept until the process ends (launches on one
  * stream run one after the other, so they share the barrier block; the count is bounded by the number of streams,
- * not of learners).  Two host threads must not call it on the SAME stream at the same time.  Process-wide; default on. */
+ * not of learners).  Two host threads must not call it on the SAME stream at the same time.  Process-wide; default 1.
+ * on = 2: trl_dqn_learn_fused_u8[_ring] also issues the four small steps between its first layer's forward and weight
+ * gradient (layer 1, layer 2, the TD loss as a one-workgroup member of the chain, the input gradients) as one launch:
+ * same bits for B <= 256 (beyond: the loss value is another fixed-order sum), measured SLOWER than the four launches
+ * (0.127 - 0.129 against 0.122 - 0.125 ms per step at B = 256 on one box: that step is device-bound), hence not part of the default. */
 void trl_offpolicy_set_chain(int32_t on);
 
 /* DQNController.learn up to the optimizer step (dqn_controller.py:61-83; the periodic hard sync

@@ -211,3 +211,41 @@ def test_dqn_learn_indexed_reads_the_ring_in_place(K, A, B, cap, pushes):
              torch.randn(64, 8, device=DEV), torch.zeros(64, 1, device=DEV))
   cf = DQNController(8, 2, device=DEV)
   assert torch.isfinite(cf.learn_indexed(dsf, torch.arange(32), in_place=True)['td_loss']).item()
+
+
+@pytest.mark.parametrize('B,double_dqn', [(256, True), (64, False), (1024, True)])
+def test_dqn_uint8_middle_chain_equals_the_launches(B, double_dqn):
+  """With trl_offpolicy_set_chain(2) the uint8 DQN step issues layer 1, layer 2, the TD loss and the input gradients as ONE
+  launch (k_chain with the loss as a one-workgroup member; opt-in: measured slower than the four launches it replaces);
+  trl_offpolicy_set_chain(0) issues them as four.  Three consecutive steps: up to 256 rows
+  the loss is the same bits (a row per thread, k_td_loss's own block sum) and so are weights and moments; beyond that the
+  loss is another fixed-order sum (1e-6) of the same rows' terms, everything else the same bits."""
+  from torchrl_amd import _lib
+  K, A = 1024, 6
+  g = torch.Generator(device=DEV).manual_seed(B)
+  batches = [(torch.randint(0, 256, (B, K), device=DEV, dtype=torch.uint8, generator=g),
+              torch.randint(0, A, (B, 1), device=DEV, generator=g).float(), torch.randn(B, 1, device=DEV, generator=g),
+              torch.randint(0, 256, (B, K), device=DEV, dtype=torch.uint8, generator=g),
+              (torch.rand(B, 1, device=DEV, generator=g) < 0.1).float()) for _ in range(3)]
+  res = []
+  try:
+    for chain in (2, 0):
+      _lib.lib().trl_offpolicy_set_chain(chain)
+      torch.manual_seed(3)
+      c = DQNController(K, A, double_dqn=double_dqn, lr=1e-3, n_update_interval=2, device=DEV, hidden=128)
+      with torch.no_grad():
+        for net in (c.q_net, c.target_q_net):
+          net.net[0].weight.mul_(1.0 / 64)
+      c._target.data.add_(1e-3)
+      losses = [c.learn(*b)['td_loss'].clone() for b in batches]
+      torch.cuda.synchronize()
+      res.append((torch.stack(losses), c._q.data.clone(), c.q_net_optim.exp_avg.clone(), c.q_net_optim.exp_avg_sq.clone()))
+  finally:
+    _lib.lib().trl_offpolicy_set_chain(1)
+  assert torch.isfinite(res[0][0]).all()
+  if B <= 256:
+    assert torch.equal(res[0][0], res[1][0])
+  else:
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=1e-7)
+  for x, y in zip(res[0][1:], res[1][1:]):
+    assert torch.equal(x, y)

@@ -101,6 +101,13 @@ struct LossArgs {
   const float *lterm, *q_pi;
   int B;
   float *losses_out;
+  // kind == 1: not sums but the whole TD loss of a DQN step (dqn_controller.py:64-78; the arithmetic of k_td_loss,
+  // trl_loss.hip) over the B rows by this one workgroup: loss -> losses_out[0], d loss / d q -> dq [B, A]
+  int kind;
+  const float *q, *qnt, *qno, *action, *reward, *done;
+  float *dq;
+  int A, td_kind;
+  float gamma, hdelta;
 };
 
 struct PhaseArgs {
@@ -476,11 +483,49 @@ __device__ __forceinline__ void ddpg_sums_body(const LossArgs &L, float *red) {
   }
 }
 
+// The TD loss of a DQN step as a member of a chain (B <= 4096 rows: one workgroup).  Row by row the arithmetic of
+// k_td_loss (trl_loss.hip); a thread's rows are added in order, then the block sum: for B <= 256 (a row a thread) the
+// same summation as k_td_loss's single block, i.e. the same bits; beyond that another fixed order.
+template <bool COH>
+__device__ __forceinline__ void dqn_td_body(const LossArgs &L, float *red) {
+  const float invB = 1.0f / (float)L.B;
+  const int A = L.A;
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < L.B; b += 256) {
+    int a = (int)ld1(L.action + b);  // action.long()
+    a = a < 0 ? 0 : (a >= A ? A - 1 : a);
+    const float *tn = L.qnt + (size_t)b * A;
+    float nq;
+    if (L.qno) {  // Double-DQN: first argmax of the online net, value from the target net
+      const float *on = L.qno + (size_t)b * A;
+      int am = 0;
+      float best = ldf<COH>(on);
+      for (int i = 1; i < A; ++i) {
+        const float x = ldf<COH>(on + i);
+        if (x > best) { best = x; am = i; }
+      }
+      nq = ldf<COH>(tn + am);
+    } else {
+      nq = ldf<COH>(tn);
+      for (int i = 1; i < A; ++i) nq = fmaxf(nq, ldf<COH>(tn + i));
+    }
+    const float y = ld1(L.reward + b) + (L.gamma * nq) * (1.0f - ld1(L.done + b));      // reward + gamma * next_q * (1 - done)
+    const float td = y - ldf<COH>(L.q + (size_t)b * A + a);
+    float g;
+    acc += trl_loss_elem(td, L.td_kind, L.hdelta, &g);
+    const float gq = -(invB * g);  // d loss / d q[b, a]
+    for (int i = 0; i < A; ++i) stf<COH>(L.dq + (size_t)b * A + i, (i == a) ? gq : 0.0f);
+  }
+  const float s = trl_block_sum<4>(acc, red);
+  if (threadIdx.x == 0) L.losses_out[0] = s * invB;
+}
+
 __global__ __launch_bounds__(256) void k_phase(PhaseArgs P) {
   __shared__ float red[4][256];
   const int wg = blockIdx.x;
   if (P.sum_extra && wg == P.wgs) {
-    ddpg_sums_body<false>(P.L, &red[0][0]);
+    if (P.L.kind == 1) dqn_td_body<false>(P.L, &red[0][0]);
+    else ddpg_sums_body<false>(P.L, &red[0][0]);
     return;
   }
   int pi = 0;
@@ -577,7 +622,8 @@ __global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ tab
           const int *lsrc = (const int *)&P.L;
 #pragma unroll
           for (int i = 0; i < (int)(sizeof(LossArgs) / 4); ++i) L.w[i] = __builtin_amdgcn_readfirstlane(lsrc[i]);
-          ddpg_sums_body<true>(L.l, &red[0][0]);
+          if (L.l.kind == 1) dqn_td_body<true>(L.l, &red[0][0]);
+          else ddpg_sums_body<true>(L.l, &red[0][0]);
           __syncthreads();
           continue;
         }
@@ -608,7 +654,7 @@ __global__ __launch_bounds__(256) void k_chain(const PhaseArgs *__restrict__ tab
           const PhaseArgs &Q = *(const PhaseArgs *)(tab + q * PW);
           if (Q.sum_extra && Q.L.losses_out) {
             Q.L.losses_out[0] = __builtin_nanf("");
-            Q.L.losses_out[1] = __builtin_nanf("");
+            if (Q.L.kind == 0) Q.L.losses_out[1] = __builtin_nanf("");
           }
         }
       return;
@@ -740,6 +786,12 @@ struct Chain {
   }
   // one more workgroup in the phase added last: the two loss values from the rows' terms
   void add_sums(const LossArgs &L) { ph[n - 1].L = L; ph[n - 1].sum_extra = 1; }
+  // a phase of its own that is one workgroup's loss body and no tiles
+  void add_loss_phase(const LossArgs &L) {
+    if (n >= MAX_PHASES) { full = true; return; }
+    memset(&ph[n], 0, sizeof(PhaseArgs));
+    ph[n].L = L; ph[n].sum_extra = 1; ++n;
+  }
 };
 
 int run_launches(const Chain &c, hipStream_t st, const char *what) {
@@ -926,7 +978,7 @@ struct DqnWs {
 
 }  // namespace
 
-extern "C" void trl_offpolicy_set_chain(int32_t on) { g_chain_on = on ? 1 : 0; }
+extern "C" void trl_offpolicy_set_chain(int32_t on) { g_chain_on = on < 0 ? 0 : (on > 2 ? 2 : on); }
 
 extern "C" int64_t trl_ddpg_learn_workspace_bytes(const trl_mlp_desc *actor, const trl_mlp_desc *critic, int64_t B) {
   if (!actor || !critic || B <= 0) return 0;
@@ -1119,6 +1171,16 @@ int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl
   const void *xs[3] = {obs, next_obs, next_obs};
   const int npass = double_dqn ? 3 : 2;
   float *u8_ws = (float *)ws + (W.floats + (trl_loss_workspace_bytes() + 3) / 4 + 63) / 64 * 64;
+  // The four small dependent steps between the first layer's forward and its weight gradient -- layer 1, layer 2, the TD
+  // loss, the input gradients -- as ONE launch (k_chain) when the first layer is the uint8 kernels' (those stay launches
+  // of their own on either side); same conditions as the DDPG chain, same bits as the launches for B <= 256.  OPT-IN
+  // (trl_offpolicy_set_chain(2)): measured slower than the four launches on the bench's step (0.127 - 0.129 against 0.122 - 0.125 ms at
+  // B = 256 on one box -- this step is bound by the device, not by the host's launches: a barrier plus a one-workgroup loss phase
+  // under 500 polling workgroups costs more than three kernel boundaries).
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  const bool mid_chain = u8 && g_chain_on >= 2 && !opt->dev_state && cap == hipStreamCaptureStatusNone && st != hipStreamPerThread;
+  Chain mid;
   for (int l = 0; l < 3; ++l) {
     if (l == 0 && u8) {
       const uint8_t *x8[3];
@@ -1137,16 +1199,26 @@ int dqn_learn_impl(const char *fn, bool u8, const trl_mlp_desc *q_net, const trl
       add_fwd(ph, B, x, nets[j]->dims[l], nullptr, 0, nets[j]->w[l], nets[j]->b[l], nets[j]->dims[l + 1],
               l < 2 ? ACT_RELU : ACT_NONE, y);
     }
-    if ((rc = launch(ph, st, fn))) return rc;
+    if (mid_chain && l >= 1) mid.add(ph);
+    else if ((rc = launch(ph, st, fn))) return rc;
   }
-  if ((rc = trl_td_loss(W.q[0], W.q[1], double_dqn ? W.q[2] : nullptr, action, reward, done, B, A, gamma, kind,
-                        huber_delta, loss_out, W.dq, loss_ws, stream)))
-    return rc;
-  {
-    Phase ph;
-    add_dx(ph, B, g_virtual(W.dq, 0.f, A, q_net->w[2], W.h1[0]), H1, q_net->w[1], H0, 0, H0, ACT_RELU, W.h0[0], H0,
-           W.g0, W.g1);
-    if ((rc = launch(ph, st, fn))) return rc;
+  Phase dx;
+  add_dx(dx, B, g_virtual(W.dq, 0.f, A, q_net->w[2], W.h1[0]), H1, q_net->w[1], H0, 0, H0, ACT_RELU, W.h0[0], H0,
+         W.g0, W.g1);
+  if (mid_chain) {
+    LossArgs L;
+    memset(&L, 0, sizeof(L));
+    L.kind = 1; L.B = B; L.losses_out = loss_out;
+    L.q = W.q[0]; L.qnt = W.q[1]; L.qno = double_dqn ? W.q[2] : nullptr; L.action = action; L.reward = reward; L.done = done;
+    L.dq = W.dq; L.A = A; L.td_kind = kind; L.gamma = (float)gamma; L.hdelta = (float)huber_delta;
+    mid.add_loss_phase(L);
+    mid.add(dx);
+    if ((rc = run_chain(mid, st, fn))) return rc;
+  } else {
+    if ((rc = trl_td_loss(W.q[0], W.q[1], double_dqn ? W.q[2] : nullptr, action, reward, done, B, A, gamma, kind,
+                          huber_delta, loss_out, W.dq, loss_ws, stream)))
+      return rc;
+    if ((rc = launch(dx, st, fn))) return rc;
   }
   if (u8) {   // layer 0 first: it reads nothing the next launch writes
     // The gradient launch fills one wave of workgroups (K / 128 of them), so an Adam epilogue would run
