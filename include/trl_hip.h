@@ -469,6 +469,14 @@ int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         int32_t A, double clip, double alpha, double beta, float *losses_out, const trl_adam_args *adam,
                         int32_t update, void *ws, void *stream);
 
+/* The same for ONE A2CController.learn step (a2c_controller.py:47-69) with A2CNet's critic and softmax actor
+ * (models.py:84-109): arguments as trl_a2c_learn_fused (action [B] = the index as f32; adv [B] = returns - V(obs)
+ * detached, computed by the caller), 2 <= A <= 4, the shapes above -- A2CNet(8, 4, 256), the reference's default width
+ * with four actions over eight observations, is one of them.  Same workspace. */
+int trl_a2c_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *obs, const float *action,
+                        const float *returns, const float *adv, int64_t B, int32_t A, double alpha, double beta,
+                        float *losses_out, const trl_adam_args *adam, int32_t update, void *ws, void *stream);
+
 /* ------------------------------------------------------------------ fused off-policy learner steps (a-2 + a-4)
  * DDPGController.learn (ddpg_controller.py:101-128) as 10 phases of one tile kernel (csrc/trl_offpolicy.hip;
  * one launch, or one per phase: trl_offpolicy_set_chain): the five

@@ -253,3 +253,40 @@ def test_learn_tiles_is_reproducible_and_gradients_only():
     outs.append((l4.clone(), ctl._flat.grad.clone()))
   assert ctl.ac_net_optim.step_count == 0                     # gradients only: nothing stepped
   assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # slabs added in a fixed order
+
+
+# ---------------------------------------------------------------- A2C through the tile pipeline (trl_a2c_learn_tiles)
+A2C_TILE_CASES = [(8, 4, (256,), 5000),       # A2CNet(8, 4, 256): the reference's default width, four actions
+                  (4, 3, (256,), 3001), (12, 2, (128,), 2500), (15, 4, (128,), 999), (3, 3, (64, 64), 70001), (6, 4, (48, 32), 131),
+                  (10, 2, (256,), 40000)]
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B', A2C_TILE_CASES)
+def test_a2c_learn_tiles_matches_oracle(obs_size, A, hidden, B):
+  """A2CController.learn for the A2CNet shapes outside the register-chained kernels (three or four actions, a wide layer
+  over 10 - 15 observations) through the tile pipeline, against the oracle's torch-CPU A2CController.learn
+  (a2c_controller.py:47-69): losses 2e-6 relative (the slabs' sums are carried in double), gradients, weights after Adam."""
+  from torchrl_amd.contrib.controllers import A2CController
+  torch.manual_seed(obs_size + 10 * A + B)
+  ctl = A2CController(obs_size, A, lr=1e-3, alpha=0.5, beta=1e-2, device=DEV, hidden=hidden)
+  assert ctl._fused is None and ctl._tiles is not None
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+  g = torch.Generator().manual_seed(B)
+  obs = torch.randn(B, obs_size, generator=g)
+  act = torch.randint(0, A, (B, 1), generator=g).float()
+  ret = torch.randn(B, 1, generator=g)
+  exp = loss_oracle.a2c_learn(ref, ref_opt, obs, act, None, None, None, ret, alpha=0.5, beta=1e-2)
+  exp_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+  got = ctl.learn(obs.to(DEV), act.to(DEV), None, None, None, ret.to(DEV))
+  torch.cuda.synchronize()
+  assert ctl.ac_net_optim.step_count == 1
+  for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+    e, v = float(exp[k]), float(got[k].cpu())
+    assert abs(v - e) <= 2e-6 * abs(e) + 2e-7, (k, v, e)
+  got_grad = ctl._flat.dense(grad=True).cpu()
+  np.testing.assert_allclose(got_grad.numpy(), exp_grad.numpy(), rtol=1e-4, atol=2e-5 * float(exp_grad.abs().max()))
+  exp_w = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+  got_w = ctl._flat.dense().cpu()
+  assert float((got_w - exp_w).abs().max()) <= 2.5e-3
+  assert float(((got_w - exp_w).abs() > 1e-5).float().mean()) < 0.02

@@ -25,10 +25,15 @@ class A2CController(Controller):
     for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
       stack.direct_grads = True
     self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); config.fused_learn = False / fused=False disables
+    self._tiles = None
     if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
       if F.FusedPpoLearn.supports(lins[0], lins[1], None):
         self._fused = F.FusedPpoLearn(lins[0], lins[1], None, products=products or config.learn_products)
+      elif F.FusedPpoLearn.tiles_supports(lins[0], lins[1], a2c=True):
+        # shapes outside the register-chained kernels (three or four actions, a wide layer over 10..15 observations):
+        # the tile pipeline spread over the chip (trl_a2c_learn_tiles, csrc/trl_epoch.hip)
+        self._tiles = F.FusedPpoLearn(lins[0], lins[1], None)
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma
@@ -97,6 +102,11 @@ class A2CController(Controller):
                                adam=self.ac_net_optim if in_kernel else None)
       if solo and not in_kernel:
         self.ac_net_optim.step()
+      return losses[:3]
+    if (self._tiles is not None and not self.ac_net_optim.device_state and obs.is_cuda and obs.dim() == 2
+        and obs.dtype == torch.float32 and obs.shape[0] >= 32):
+      losses = self._tiles.a2c_tiles(obs, action, returns, self.alpha, self.beta, self.ac_net_optim,
+                                     update=not self._sync.enabled)
       return losses[:3]
     value, probs = self.ac_net.heads(obs)
     loss, parts = F.a2c_loss(probs, value, action, returns, self.alpha, self.beta)

@@ -287,8 +287,11 @@ __global__ void k_epoch_totals(float *losses, int K, float alpha, float beta) {
   if (k < K) losses[4 * k + 3] = (losses[4 * k] + alpha * losses[4 * k + 1]) - beta * losses[4 * k + 2];
 }
 
-// role: 0 critic, 1 actor; D3: two hidden layers; O: the network's fan-out
-template <int role, bool D3, int O, bool TILES>
+// role: 0 critic, 1 actor; D3: two hidden layers; O: the network's fan-out; KIND: 0 PPO (Normal policy, clipped
+// surrogate), 1 A2C (softmax policy, adv * log-prob: a2c_controller.py:48-59 in k_a2c_loss's arithmetic; tiles mode only)
+constexpr float F32_EPS = 1.1920928955078125e-07f;        // torch.finfo(torch.float32).eps
+constexpr float F32_LOWEST = -3.4028234663852886e+38f;
+template <int role, bool D3, int O, bool TILES, int KIND = 0>
 __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   const Net &N = P.net[role];
   const Lay L = make_lay(N);
@@ -418,8 +421,12 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         in_ret = ok ? P.returns[r] : 0.f;
       } else {
         in_adv = ok ? P.adv[r] : 0.f;
+        if (KIND == 1) {
+          in_act[0] = ok ? P.action[r] : 0.f;      // the action's index
+        } else {
 #pragma unroll
-        for (int a = 0; a < O; ++a) { in_act[a] = ok ? P.action[r * O + a] : 0.f; in_old[a] = ok ? P.old_logp[r * O + a] : 0.f; }
+          for (int a = 0; a < O; ++a) { in_act[a] = ok ? P.action[r * O + a] : 0.f; in_old[a] = ok ? P.old_logp[r * O + a] : 0.f; }
+        }
       }
     }
   };
@@ -643,6 +650,45 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           a_crit += ok ? dv * dv : 0.f;
           a_gb[0] += g;
           gout[lane] = g;
+        } else if (KIND == 1) {
+          // out = the actor's logits; nn.Softmax(dim=1) (models.py:99-103), Categorical(probs), the loss of
+          // a2c_controller.py:48-59; cur_adv is the detached advantage returns - V(obs) (the caller's forward pass)
+          float zmax = out[0];
+#pragma unroll
+          for (int n = 1; n < O; ++n) zmax = fmaxf(zmax, out[n]);
+          float pr[O], esum = 0.f;
+#pragma unroll
+          for (int n = 0; n < O; ++n) { pr[n] = expf(out[n] - zmax); esum += pr[n]; }
+          float sp = 0.f;
+#pragma unroll
+          for (int n = 0; n < O; ++n) { pr[n] = pr[n] / esum; sp += pr[n]; }      // Categorical: probs / probs.sum(-1, keepdim=True)
+          int ai = (int)cur_act[0];      // action.long()
+          ai = ai < 0 ? 0 : (ai >= O ? O - 1 : ai);
+          float ent = 0.f, gdot = 0.f, logp = 0.f, gg[O];
+#pragma unroll
+          for (int n = 0; n < O; ++n) {
+            const float pn = pr[n] / sp;
+            const float cl = fminf(fmaxf(pn, F32_EPS), 1.0f - F32_EPS);      // clamp_probs
+            const float logit = logf(cl);
+            ent += fmaxf(logit, F32_LOWEST) * pn;
+            if (n == ai) logp = logit;
+            const float dlogit = (pn >= F32_EPS && pn <= 1.0f - F32_EPS) ? 1.0f / cl : 0.f;
+            float g1 = (P.beta * invB) * (logit + pn * dlogit);      // from -beta * entropy
+            if (n == ai) g1 += (-(cur_adv * invB)) * dlogit;          // from the actor term
+            gg[n] = g1;
+            gdot += g1 * pn;
+          }
+          float dp[O], dsum = 0.f;
+#pragma unroll
+          for (int n = 0; n < O; ++n) { dp[n] = (gg[n] - gdot) / sp; dsum += dp[n] * pr[n]; }      // back through the normalisation
+#pragma unroll
+          for (int n = 0; n < O; ++n) {
+            const float g = ok ? (dp[n] - dsum) * pr[n] : 0.f;      // softmax backward
+            a_gb[n] += g;
+            gout[n * LS + lane] = g;
+          }
+          a_min += ok ? cur_adv * logp : 0.f;
+          a_ent += ok ? -ent : 0.f;
         } else {
           const float gmin = -(1.0f / (float)(nb * O));
 #pragma unroll
@@ -808,7 +854,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           const float gb = trl_wave_sum(a_gb[a]), gl = trl_wave_sum(a_dls[a]);
           if (lane == 0) {
             tailg[a] = gb;
-            tailg[L.o_ls - L.o_bl + a] = gl + ent_share;
+            if (KIND == 0) tailg[L.o_ls - L.o_bl + a] = gl + ent_share;      // (A2C: no log_std)
           }
         }
       }
@@ -1043,11 +1089,11 @@ __global__ __launch_bounds__(NT) void k_ppo_epoch(const Args P) {
 
 // One big batch: workgroup (role = blockIdx.x, g = blockIdx.y) carries slab g of the rows through the same tile pipeline
 // and leaves its partial gradient sums; k_tiles_reduce adds the slabs in order and applies clip_grad_value_ + Adam.
-template <bool D3, int AO>
+template <bool D3, int AO, int KIND = 0>
 __global__ __launch_bounds__(NT) void k_ppo_tiles(const Args P) {
   extern __shared__ __align__(16) float lds[];
-  if (blockIdx.x == 0) epoch_body<0, D3, 1, true>(P, lds);
-  else epoch_body<1, D3, AO, true>(P, lds);
+  if (blockIdx.x == 0) epoch_body<0, D3, 1, true, KIND>(P, lds);
+  else epoch_body<1, D3, AO, true, KIND>(P, lds);
 }
 
 struct Segs {
@@ -1127,6 +1173,14 @@ EpochKernel pick_kernel(bool d3, int A) {
     case 2: return d3 ? k_ppo_epoch<true, 2> : k_ppo_epoch<false, 2>;
     case 3: return d3 ? k_ppo_epoch<true, 3> : k_ppo_epoch<false, 3>;
     default: return d3 ? k_ppo_epoch<true, 4> : k_ppo_epoch<false, 4>;
+  }
+}
+
+EpochKernel pick_tiles_kernel_a2c(bool d3, int A) {
+  switch (A) {
+    case 2: return d3 ? k_ppo_tiles<true, 2, 1> : k_ppo_tiles<false, 2, 1>;
+    case 3: return d3 ? k_ppo_tiles<true, 3, 1> : k_ppo_tiles<false, 3, 1>;
+    default: return d3 ? k_ppo_tiles<true, 4, 1> : k_ppo_tiles<false, 4, 1>;
   }
 }
 
@@ -1288,17 +1342,19 @@ extern "C" int64_t trl_ppo_learn_tiles_workspace_bytes(int64_t n_flat, int64_t B
   return ((int64_t)G * n_flat + 2 * (int64_t)G * 4 + 64) * (int64_t)sizeof(float);
 }
 
-extern "C" int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
-                                   const float *obs, const float *action, const float *returns, const float *old_logp,
-                                   const float *adv, int64_t B, int32_t A, double clip, double alpha, double beta,
-                                   float *losses_out, const trl_adam_args *adam, int32_t update, void *ws, void *stream) {
-  const char *fn = "trl_ppo_learn_tiles";
+namespace {
+// kind 0: PPO (log_std, old_logp, action [B, A]); kind 1: A2C (softmax actor, action [B] = the index, no log_std / old_logp)
+int learn_tiles_impl(const char *fn, int kind, const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                     const float *obs, const float *action, const float *returns, const float *old_logp,
+                     const float *adv, int64_t B, int32_t A, double clip, double alpha, double beta,
+                     float *losses_out, const trl_adam_args *adam, int32_t update, void *ws, void *stream) {
   TRL_REQUIRE(adam && adam->param && adam->grad && adam->n > 0, "%s: the optimizer block (flat buffers) is required", fn);
   TRL_REQUIRE(!update || (adam->exp_avg && adam->exp_avg_sq && adam->step >= 1 && !adam->dev_state),
               "%s: update needs the moment buffers and a host step count >= 1", fn);
-  TRL_REQUIRE(A >= 1 && A <= MAXO, "%s: action size %d must be in [1, %d]", fn, A, MAXO);
+  TRL_REQUIRE(A >= (kind == 1 ? 2 : 1) && A <= MAXO, "%s: action size %d must be in [%d, %d]", fn, A, kind == 1 ? 2 : 1, MAXO);
   TRL_REQUIRE(B >= 1 && B <= (1ll << 31) - 64, "%s: bad batch size", fn);
-  TRL_REQUIRE(obs && action && returns && old_logp && adv && losses_out && log_std && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(obs && action && returns && adv && losses_out && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(kind == 1 || (old_logp && log_std), "%s: NULL argument", fn);
   TRL_REQUIRE(((uintptr_t)ws & 15) == 0, "%s: the workspace must be 16 B aligned", fn);
   Args P = {};
   int rc;
@@ -1306,8 +1362,8 @@ extern "C" int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_des
     return rc;
   TRL_REQUIRE(P.net[0].d0 == P.net[1].d0 && P.net[0].depth == P.net[1].depth,
               "%s: critic and actor must have the same fan-in and depth", fn);
-  const int64_t lo = log_std - adam->param;
-  TRL_REQUIRE(lo >= 0 && lo + A <= adam->n, "%s: log_std must lie inside the optimizer's flat buffer", fn);
+  const int64_t lo = kind == 1 ? -1 : log_std - adam->param;
+  TRL_REQUIRE(kind == 1 || (lo >= 0 && lo + A <= adam->n), "%s: log_std must lie inside the optimizer's flat buffer", fn);
   P.net[1].ls_off = lo;
   int64_t lds_bytes = 0;
   for (int r = 0; r < 2; ++r) {
@@ -1328,7 +1384,7 @@ extern "C" int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_des
   P.lpart = P.gpart + (size_t)G * adam->n;
   P.losses = losses_out;
   hipStream_t st = (hipStream_t)stream;
-  EpochKernel kern = pick_tiles_kernel(P.net[0].depth == 3, A);
+  EpochKernel kern = kind == 1 ? pick_tiles_kernel_a2c(P.net[0].depth == 3, A) : pick_tiles_kernel(P.net[0].depth == 3, A);
   if (lds_bytes > 48 * 1024 &&
       hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess) {
     (void)hipGetLastError();
@@ -1348,15 +1404,33 @@ extern "C" int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_des
       add(P.net[r].w_off[l], (int64_t)nets[r]->dims[l + 1] * nets[r]->dims[l]);
       add(P.net[r].b_off[l], nets[r]->dims[l + 1]);
     }
-  add(lo, A);
+  if (kind == 0) add(lo, A);
   TrlAdamScalars sc = {};
   if (update) sc = trl_adam_scalars(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->grad_scale, adam->clip_value);
   const int total = sg.start[sg.n];
   hipLaunchKernelGGL(k_tiles_reduce, dim3((total + 255) / 256), dim3(256), 0, st, (const float *)P.gpart, (const float *)P.lpart, G,
-                     P.n_flat, sg, adam->param, adam->grad, adam->exp_avg, adam->exp_avg_sq, sc, update ? 1 : 0, B, (int)A,
+                     P.n_flat, sg, adam->param, adam->grad, adam->exp_avg, adam->exp_avg_sq, sc, update ? 1 : 0, B,
+                     kind == 1 ? 1 : (int)A,      // (A2C's actor and entropy terms are means over the batch, PPO's over [B, A])
                      losses_out);
   TRL_CHECK_LAUNCH(fn);
   hipLaunchKernelGGL(k_tiles_total, dim3(1), dim3(64), 0, st, losses_out, P.alpha, P.beta);
   TRL_CHECK_LAUNCH(fn);
   return TRL_OK;
+}
+}  // namespace
+
+extern "C" int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                   const float *obs, const float *action, const float *returns, const float *old_logp,
+                                   const float *adv, int64_t B, int32_t A, double clip, double alpha, double beta,
+                                   float *losses_out, const trl_adam_args *adam, int32_t update, void *ws, void *stream) {
+  return learn_tiles_impl("trl_ppo_learn_tiles", 0, critic, actor, log_std, obs, action, returns, old_logp, adv, B, A, clip,
+                          alpha, beta, losses_out, adam, update, ws, stream);
+}
+
+extern "C" int trl_a2c_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *obs,
+                                   const float *action, const float *returns, const float *adv, int64_t B, int32_t A,
+                                   double alpha, double beta, float *losses_out, const trl_adam_args *adam, int32_t update,
+                                   void *ws, void *stream) {
+  return learn_tiles_impl("trl_a2c_learn_tiles", 1, critic, actor, nullptr, obs, action, returns, nullptr, adv, B, A, 0.0,
+                          alpha, beta, losses_out, adam, update, ws, stream);
 }

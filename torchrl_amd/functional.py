@@ -938,6 +938,64 @@ class FusedPpoLearn:
           losses.data_ptr(), C.byref(a), 1 if update else 0, ws.data_ptr(), _lib.stream_ptr(dev)))
     return losses
 
+  @staticmethod
+  def tiles_supports(critic_lin, actor_lin, a2c=False):
+    """Shapes the tile pipeline takes for one step over a batch of any size (trl_ppo_learn_tiles / trl_a2c_learn_tiles):
+    one hidden layer (a multiple of 16, <= 256) or two (<= 64) over at most 15 observations, up to four actions
+    (A2C: at least two), float32 parameters on a HIP device."""
+    if len(critic_lin) != len(actor_lin) or len(critic_lin) not in (2, 3):
+      return False
+    A = actor_lin[-1].out_features
+    if critic_lin[-1].out_features != 1 or not (2 if a2c else 1) <= A <= 4:
+      return False
+    K0 = critic_lin[0].in_features
+    if K0 != actor_lin[0].in_features or K0 > 15:
+      return False
+    for lin in (critic_lin, actor_lin):
+      hid = [m.out_features for m in lin[:-1]]
+      if any(h % 16 or h < 16 for h in hid) or (len(hid) == 1 and hid[0] > 256) or (len(hid) == 2 and max(hid) > 64):
+        return False
+      if any(m.bias is None or m.weight.dtype != torch.float32 or not m.weight.is_cuda for m in lin):
+        return False
+    return True
+
+  def a2c_tiles(self, obs, action, returns, alpha, beta, adam, update=True):
+    """A2CController.learn's device work through the tile pipeline (trl_a2c_learn_tiles) for the A2CNet shapes the
+    register-chained kernels do not take (three or four actions, a wide layer over 10 - 15 observations): the detached
+    advantage returns - V comes from the forward-only kernel where it takes the shape, else from the critic module.
+    Returns the [4] loss tensor."""
+    C = self._C
+    B = obs.shape[0]
+    obs = _f32c(obs, 'obs')
+    action = _f32c(action, 'action')
+    returns = _f32c(returns, 'returns')
+    if obs.dim() != 2 or obs.shape[1] != self.K0 or action.numel() != B or returns.numel() != B:
+      raise ValueError('a2c_learn_tiles: inconsistent shapes')
+    if self._ptr_key() != self._key:
+      self._bind()
+    with torch.no_grad():
+      if self.K0 <= 9 or (len(self.critic_lin) == 3 and self.K0 <= 12):
+        value = self.forward(obs, want_mean=False)[0]
+      else:
+        h = obs
+        for i, m in enumerate(self.critic_lin):
+          h = torch.nn.functional.linear(h, m.weight, m.bias)
+          if i + 1 < len(self.critic_lin):
+            h = torch.relu(h)
+        value = h.view(-1)
+      adv = (returns.view(-1) - value).contiguous()
+    dev = obs.device
+    lib = _lib.lib()
+    a = adam.fused_args(update)
+    ws = self._ws.get(dev, lib.trl_ppo_learn_tiles_workspace_bytes(a.n, B))
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+      _lib.check(lib.trl_a2c_learn_tiles(
+          C.byref(self.descs[0]), C.byref(self.descs[1]), obs.data_ptr(), action.data_ptr(), returns.data_ptr(),
+          adv.data_ptr(), B, self.A, float(alpha), float(beta), losses.data_ptr(), C.byref(a), 1 if update else 0,
+          ws.data_ptr(), _lib.stream_ptr(dev)))
+    return losses
+
   def a2c(self, obs, action, returns, alpha, beta, adam=None):
     """A2CController.learn's device work for A2CNet stacks (trl_a2c_learn_fused): a forward-only
     pass gives the detached advantage returns - V, then one launch for forward + loss + backward
