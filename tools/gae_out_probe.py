@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+bench._load()
 from torchrl_amd import functional as F  # noqa: E402
 
 T, N = 2048, 4096

@@ -9,6 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('TRL_LIB', 'tune')   # the -DTRL_TUNING diagnostic build (python -m torchrl_amd._build --tuning)
 import bench  # noqa: E402
+bench._load()
 from torchrl_amd import _lib  # noqa: E402
 from torchrl_amd.contrib.controllers import DQNController  # noqa: E402
 
