@@ -170,6 +170,39 @@ def test_ddpg_split_step_equals_in_kernel_update_golden(golden, rccl_world1, mon
         _close(sub(f.dense().cpu().numpy()), g['%sstep%d_%s' % (p, step, nm)], 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize('ctl', ['ppo', 'a2c'])
+def test_bf16x6_split_step_equals_in_kernel_update(ctl, rccl_world1, monkeypatch):
+  """The second product variant (products='bf16x6', csrc/trl_learn.hip: k_ac_learn_pair_bx) under the N-rank call
+  sequence: the gradients-only launch + all-reduce + trl_adam_step give the bits of its in-kernel update (what
+  `bench.py --gpus N` runs on every rank; the exact variant is covered by the golden tests above)."""
+  B = 8 * 32 * 128 + 640
+  if ctl == 'ppo':
+    make = lambda: PPOController(3, 1, lr=3e-4, beta=1e-2, max_grad_norm=0.05, device=DEV, hidden=(64, 64), products='bf16x6')
+  else:
+    make = lambda: A2CController(4, 2, lr=1e-3, beta=1e-2, device=DEV, hidden=(64, 64), products='bf16x6')
+  torch.manual_seed(11)
+  solo, split = _pair(make, monkeypatch)
+  split._flat.data.copy_(solo._flat.data)
+  assert solo._fused is not None and solo._fused.bx6_takes(B) and split._fused.bx6_takes(B)
+  gen = torch.Generator(device=DEV).manual_seed(12)
+  for step in range(2):
+    ret = torch.randn(B, 1, device=DEV, generator=gen)
+    if ctl == 'ppo':
+      obs, act = torch.randn(B, 3, device=DEV, generator=gen), torch.randn(B, 1, device=DEV, generator=gen)
+      old, adv = torch.randn(B, 1, device=DEV, generator=gen) - 1.0, torch.randn(B, 1, device=DEV, generator=gen)
+      batch = (obs, act, None, None, None, ret, old, adv)
+    else:
+      obs = torch.randn(B, 4, device=DEV, generator=gen)
+      act = torch.randint(0, 2, (B, 1), device=DEV, generator=gen).float()
+      batch = (obs, act, None, None, None, ret)
+    i1, i2 = solo.learn(*batch), split.learn(*batch)
+    for k in ('actor_loss', 'critic_loss', 'entropy_loss'):
+      _same(i1[k], i2[k], k)
+    _same(solo._flat.grad, split._flat.grad, 'gradient')
+    _same(solo._flat.data, split._flat.data, 'weights after Adam')
+    _same(solo.ac_net_optim.exp_avg_sq, split.ac_net_optim.exp_avg_sq, 'second moment')
+
+
 def test_ppo_scale_then_clamp_after_the_reduction(rccl_world1, monkeypatch):
   """grad_scale (1 / world_size) and clip_grad_value_ are applied to the REDUCED gradient, scale first: the update
   of a 2-rank run whose ranks hold the same half-batch gradient g is Adam on clamp(0.5 * (g + g))."""
