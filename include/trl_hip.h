@@ -455,12 +455,15 @@ int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         double beta, float *losses_out, const trl_adam_args *adam, void *ws, void *stream);
 
 /* ONE PPOController.learn step (ppo_controller.py:53-80) over a batch of any size through the tile pipeline of
- * trl_ppo_learn_epoch, spread over the chip: 128 slabs of the batch x two workgroups (critic, actor), each leaving its
- * partial gradient sums, then one reduce launch that adds the slabs in order, writes every gradient to its place in
- * adam->grad and (update != 0) applies clip_grad_value_ + Adam as trl_adam_step does.  The general whole-step path:
- * it takes every shape trl_ppo_learn_epoch takes (fan-in <= 15, 1..4 actions, one hidden layer up to 256 wide or two up
- * to 64) -- in particular the ones trl_ppo_learn_fused's register-chained kernels do not (more than two actions, a
- * 256-wide layer over 10..15 observations) and that would otherwise run layer by layer.  Arguments as
+ * trl_ppo_learn_epoch, spread over the chip: slabs of the batch x two kinds of workgroup (critic, actor), each leaving
+ * its partial gradient sums, then one reduce launch that adds the slabs in order, writes every gradient to its place in
+ * adam->grad and (update != 0) applies clip_grad_value_ + Adam as trl_adam_step does.  128 slabs and both kinds in one
+ * launch; from 32,768 rows on 256 slabs and one launch per kind (the actor's workgroups take longer than the critic's:
+ * in one launch half the chip would wait for the other).  The general whole-step path: it takes every shape
+ * trl_ppo_learn_epoch takes (fan-in <= 15, 1..4 actions, one hidden layer up to 256 wide or two up to 64) and, with ONE
+ * hidden layer, fan-in up to 31 and up to six actions (ActorCriticNet(17, 6, 256): a second k round in the layer-0
+ * products) -- in particular the shapes trl_ppo_learn_fused's register-chained kernels do not take (more than two
+ * actions, a 256-wide layer over more than 9 observations) and that would otherwise run layer by layer.  Arguments as
  * trl_ppo_learn_fused; losses_out[0..3]; adam->step = the 1-based count of this update when update != 0.
  * `ws`: trl_ppo_learn_tiles_workspace_bytes(adam->n, B) bytes. */
 int64_t trl_ppo_learn_tiles_workspace_bytes(int64_t n_flat, int64_t B);
@@ -470,9 +473,11 @@ int trl_ppo_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         int32_t update, void *ws, void *stream);
 
 /* The same for ONE A2CController.learn step (a2c_controller.py:47-69) with A2CNet's critic and softmax actor
- * (models.py:84-109): arguments as trl_a2c_learn_fused (action [B] = the index as f32; adv [B] = returns - V(obs)
- * detached, computed by the caller), 2 <= A <= 4, the shapes above -- A2CNet(8, 4, 256), the reference's default width
- * with four actions over eight observations, is one of them.  Same workspace. */
+ * (models.py:84-109): arguments as trl_a2c_learn_fused (action [B] = the index as f32), 2 <= A <= 6, the shapes above --
+ * A2CNet(8, 4, 256), the reference's default width with four actions over eight observations, is one of them.
+ * adv [B] = returns - V(obs) detached (a2c_controller.py:49), computed by the caller -- or NULL: then the critic's
+ * workgroups, launched ahead of the actor's, compute it from their own forward pass (no separate value pass).
+ * Same workspace. */
 int trl_a2c_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *obs, const float *action,
                         const float *returns, const float *adv, int64_t B, int32_t A, double alpha, double beta,
                         float *losses_out, const trl_adam_args *adam, int32_t update, void *ws, void *stream);

@@ -203,7 +203,10 @@ def test_fast_adam_is_trl_adam_elem_bit_for_bit():
 
 # ---------------------------------------------------------------- one big batch through the tile pipeline (trl_ppo_learn_tiles)
 TILE_CASES = [(8, 4, (128,), 5000), (12, 3, (256,), 3000), (15, 1, (64, 64), 70001), (3, 4, (48, 32), 999), (10, 2, (256,), 40000),
-              (3, 1, (64, 64), 65536), (4, 2, (256,), 131), (2, 3, (16,), 64)]
+              (3, 1, (64, 64), 65536), (4, 2, (256,), 131), (2, 3, (16,), 64),
+              # the wide form (one hidden layer, two k rounds at layer 0, up to six outputs)
+              (17, 6, (256,), 5000),      # ActorCriticNet(17, 6, 256): the reference's default width on a MuJoCo-sized task
+              (24, 4, (256,), 3001), (31, 1, (64,), 999), (16, 2, (128,), 40000), (3, 6, (32,), 131), (8, 5, (256,), 70001)]
 
 
 @pytest.mark.parametrize('obs_size,A,hidden,B', TILE_CASES)
@@ -213,7 +216,7 @@ def test_learn_tiles_matches_oracle(obs_size, A, hidden, B):
   layer; here against the oracle's torch-CPU learn(): tests/test_gpu_learn.py's bars (losses 1e-6, clipped gradients
   1e-4 / 2e-5 of the largest, weights within 2.5 lr and < 2 % further than 1e-5)."""
   ctl = _make(obs_size, A, hidden, obs_size + 10 * A + B)
-  assert ctl._epoch is not None
+  assert ctl._tiles is not None and (ctl._epoch is not None or obs_size > 15 or A > 4)
   ref = copy.deepcopy(ctl.ac_net).cpu()
   ref_opt = torch.optim.Adam(ref.parameters(), lr=LR)
   obs, act, ret, old, adv = _data(obs_size, A, B, 7 + B, ref)
@@ -224,7 +227,7 @@ def test_learn_tiles_matches_oracle(obs_size, A, hidden, B):
   if ctl._fused is None:
     got = ctl.learn(*cols)                      # the controller's own dispatch
   else:                                         # a shape the register-chained kernel takes too: call the tile path itself
-    l4 = ctl._epoch.learn_tiles(cols[0], cols[1], cols[5], cols[6], cols[7], 0.2, 0.5, 1e-2, ctl.ac_net_optim)
+    l4 = ctl._tiles.learn_tiles(cols[0], cols[1], cols[5], cols[6], cols[7], 0.2, 0.5, 1e-2, ctl.ac_net_optim)
     got = dict(actor_loss=l4[0], critic_loss=l4[1], entropy_loss=l4[2])
     tot = float(l4[3].cpu())
     assert abs(tot - (float(l4[0]) + 0.5 * float(l4[1]) - 1e-2 * float(l4[2]))) <= 1e-6 * abs(tot) + 1e-7
@@ -258,7 +261,9 @@ def test_learn_tiles_is_reproducible_and_gradients_only():
 # ---------------------------------------------------------------- A2C through the tile pipeline (trl_a2c_learn_tiles)
 A2C_TILE_CASES = [(8, 4, (256,), 5000),       # A2CNet(8, 4, 256): the reference's default width, four actions
                   (4, 3, (256,), 3001), (12, 2, (128,), 2500), (15, 4, (128,), 999), (3, 3, (64, 64), 70001), (6, 4, (48, 32), 131),
-                  (10, 2, (256,), 40000)]
+                  (10, 2, (256,), 40000),
+                  # the wide form
+                  (17, 6, (256,), 5000), (20, 2, (128,), 3001), (8, 5, (64,), 999), (31, 3, (256,), 40000)]
 
 
 @pytest.mark.parametrize('obs_size,A,hidden,B', A2C_TILE_CASES)

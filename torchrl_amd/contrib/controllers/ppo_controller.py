@@ -32,6 +32,7 @@ class PPOController(Controller):
     for stack in (self.ac_net.critic, self.ac_net.actor):     # one use per backward, zeroed grads: let the fused backward write .grad itself
       stack.direct_grads = True
     self._epoch = None
+    self._tiles = None
     self._fused = None    # whole-step kernel for <= 64-wide stacks (csrc/trl_learn.hip); config.fused_learn = False / fused=False disables
     if self.device.type == 'cuda' and (config.fused_learn if fused is None else fused):
       lins = [[m for m in stack if isinstance(m, torch.nn.Linear)] for stack in (self.ac_net.critic, self.ac_net.actor)]
@@ -43,6 +44,11 @@ class PPOController(Controller):
       elif F.FusedPpoLearn.epoch_supports(lins[0], lins[1], self.ac_net.log_std):
         cand = F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
         self._epoch = cand if cand.epoch_supported() else None
+      # one big batch through the tile pipeline (learn_tiles): the epoch kernel's shapes and, with one hidden layer, up to 31
+      # observations and six actions (ActorCriticNet(17, 6, 256))
+      self._tiles = self._epoch
+      if self._tiles is None and F.FusedPpoLearn.tiles_supports(lins[0], lins[1]):
+        self._tiles = self._fused if self._fused is not None else F.FusedPpoLearn(lins[0], lins[1], self.ac_net.log_std)
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
 
     self.gamma = gamma
@@ -146,11 +152,11 @@ class PPOController(Controller):
       if solo and not in_kernel:
         self.ac_net_optim.step()
       return losses[:3]
-    if (self._epoch is not None and not self.ac_net_optim.device_state and obs.is_cuda and obs.dim() == 2
+    if (self._tiles is not None and not self.ac_net_optim.device_state and obs.is_cuda and obs.dim() == 2
         and obs.shape[0] >= self.TILES_MIN_BATCH):
-      # shapes outside the register-chained kernels (e.g. three or four actions, a 256-wide layer over 10..15 observations):
+      # shapes outside the register-chained kernels (e.g. three to six actions, a 256-wide layer over 10..31 observations):
       # the tile pipeline spread over the chip instead of the layer-by-layer path
-      losses = self._epoch.learn_tiles(obs, action, returns, old_log_probs, advantages, self.clip_ratio, self.alpha,
+      losses = self._tiles.learn_tiles(obs, action, returns, old_log_probs, advantages, self.clip_ratio, self.alpha,
                                        self.beta, self.ac_net_optim, update=not self._sync.enabled)
       return losses[:3]
     value, mean, log_std = self.ac_net.heads(obs)

@@ -45,8 +45,11 @@ constexpr int G0 = U0 / 4;          // groups of four layer-0 parameters a threa
 constexpr int S = 64;               // samples per tile
 constexpr int LS = S + 4;           // row stride (floats) of every 64-column LDS image: 16 lanes x 16 B on 16 distinct bank quads
 constexpr int KP = 16;              // fan-in + 1 (the bias column), padded to one k round
-constexpr int LDK = KP + 4;
 constexpr int MAXO = 4;
+// the tile pipeline's wide form (k_ppo_tiles<..., KPW>, one hidden layer, one batch spread over the chip): two k rounds at
+// layer 0 (fan-in + bias up to 32) and up to six outputs
+constexpr int KPW = 32;
+constexpr int MAXO_T = 6;
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;   // math.log(math.sqrt(2 * math.pi))
 constexpr float ENT_CONST = 1.41893853320467274178f;      // 0.5 + 0.5 * math.log(2 * math.pi)
 
@@ -72,6 +75,10 @@ struct Args {
   int64_t slab;
   float *gpart, *lpart;      // lpart: [2][G][4]
   int64_t n_flat;
+  // k_ppo_tiles launched one role at a time (A2C without a caller-supplied advantage): the critic's workgroups write
+  // adv_out[row] = returns[row] - V(row) on their way, the actor's launch behind them reads it as `adv`
+  int role_base;
+  float *adv_out;
 };
 
 // LDS map of one workgroup (offsets in floats).  Aliases: g2 (the [sample][feature] copy of layer 1's output gradient)
@@ -82,8 +89,13 @@ struct Lay {
   int HL, HLP, NB, wpb, nred, NV, o_bl, o_b1, o_ls, PO;
 };
 
-__host__ __device__ inline Lay make_lay(const Net &n) {
+__host__ __device__ inline Lay make_lay(const Net &n, int kp = KP) {
   Lay L;
+  const int ldk = kp + 4;
+  // the wide form runs in tiles mode only (no update in the kernel: no moments, layer 0's gradient leaves the accumulators
+  // for the partial buffer directly) and keeps the partial sums of the lane = feature pass over the x' images, which are
+  // dead by then -- what makes 256 units with 32 columns and six outputs fit the 160 KB
+  const bool wide = kp > KP;
   int o = 0;
   auto take = [&](int f) { int at = o; o += (f + 3) / 4 * 4; return at; };
   const bool d3 = n.depth == 3;
@@ -95,18 +107,18 @@ __host__ __device__ inline Lay make_lay(const Net &n) {
   // hidden layer -> a wave sums over its own tiles first, slot = w >> 2
   L.nred = d3 ? L.HL / 16 : (L.HL / 16 < NW / 4 ? L.HL / 16 : NW / 4);
   L.PO = n.O + (d3 ? 1 : 0);                         // partial-sum planes: dwL[o] and (two hidden layers) db1
-  L.xp[0] = take(S * LDK);
-  L.xp[1] = take(S * LDK);
-  L.xpt[0] = take(KP * LS);
-  L.xpt[1] = take(KP * LS);
-  L.w0p = take(n.H1 * LDK);
+  L.xp[0] = take(S * ldk);
+  L.xp[1] = take(S * ldk);
+  L.xpt[0] = take(kp * LS);
+  L.xpt[1] = take(kp * LS);
+  L.w0p = take(n.H1 * ldk);
   const int part_f = L.wpb * L.PO * L.HLP;
   if (d3) {
     L.h1 = take(S * LS);
     L.h1t = take(n.H1 * LS);
     if (part_f > o - L.h1) o = L.h1 + (part_f + 3) / 4 * 4;
     L.part = L.h1;
-    L.h2t = take(n.H2 * LS > n.H1 * LDK ? n.H2 * LS : n.H1 * LDK);
+    L.h2t = take(n.H2 * LS > n.H1 * ldk ? n.H2 * LS : n.H1 * ldk);
     L.gw0 = L.h2t;
     L.g1t = take(n.H1 * LS);
     L.w1 = take(n.H2 * LS);
@@ -117,8 +129,13 @@ __host__ __device__ inline Lay make_lay(const Net &n) {
     L.h2t = L.h1t;
     L.g1t = L.h1t;
     L.w1 = L.w1t = 0;
-    L.part = take(part_f);
-    L.gw0 = take(n.H1 * LDK);
+    if (wide) {
+      L.part = L.xp[0];      // part_f <= 512 PO <= 2 S ldk for every width (PO <= 6)
+      L.gw0 = L.w0p;         // (not used)
+    } else {
+      L.part = take(part_f);
+      L.gw0 = take(n.H1 * ldk);
+    }
   }
   L.red = take(L.nred * n.O * LS);
   L.gout = take(n.O * LS);
@@ -129,8 +146,8 @@ __host__ __device__ inline Lay make_lay(const Net &n) {
   L.o_ls = L.o_bl + n.O;
   L.NV = L.o_ls + (n.ls_off >= 0 ? n.O : 0);
   L.vp_p = take(L.NV);
-  L.vp_m = take(L.NV);
-  L.vp_v = take(L.NV);
+  L.vp_m = wide ? L.vp_p : take(L.NV);
+  L.vp_v = wide ? L.vp_p : take(L.NV);
   L.tail_g = take(L.NV - L.o_bl);
   L.total = o;
   return L;
@@ -291,10 +308,13 @@ __global__ void k_epoch_totals(float *losses, int K, float alpha, float beta) {
 // surrogate), 1 A2C (softmax policy, adv * log-prob: a2c_controller.py:48-59 in k_a2c_loss's arithmetic; tiles mode only)
 constexpr float F32_EPS = 1.1920928955078125e-07f;        // torch.finfo(torch.float32).eps
 constexpr float F32_LOWEST = -3.4028234663852886e+38f;
-template <int role, bool D3, int O, bool TILES, int KIND = 0>
+template <int role, bool D3, int O, bool TILES, int KIND = 0, int KPT = 16>
 __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
+  constexpr int KP = KPT, LDK = KP + 4, CT = KP / 16;      // (these shadow the file's: the wide form's x' images have 32 columns)
+  constexpr bool WIDE = KP > 16;
+  static_assert(!WIDE || (TILES && !D3), "the wide form is tiles mode, one hidden layer");
   const Net &N = P.net[role];
-  const Lay L = make_lay(N);
+  const Lay L = make_lay(N, KP);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, q = lane >> 4;
   const int H1 = N.H1, H2 = N.H2, HL = L.HL, d0 = N.d0;
   float *w0p = lds + L.w0p, *gw0 = lds + L.gw0, *h1 = lds + L.h1, *h1t = lds + L.h1t, *h2t = lds + L.h2t, *g1t = lds + L.g1t,
@@ -337,7 +357,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   const int n0e = H1 * KP;
   const int C0 = d0 + 1, n0v = H1 * C0;
   auto w0_global = [&](int e) -> int64_t {
-    const int n = e >> 4, j = e & 15;
+    const int n = e / KP, j = e % KP;
     return j < d0 ? N.w_off[0] + (int64_t)n * d0 + j : (j == d0 ? N.b_off[0] + n : -1);
   };
   v4f m0[G0], v0[G0];
@@ -359,8 +379,14 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   };
   for (int e = tid; e < H1 * LDK; e += NT) w0p[e] = 0.f;      // (the padding columns stay zero for good)
   __syncthreads();
+  if (WIDE) {
+    for (int e = tid; e < n0v; e += NT) {
+      const int n = e / C0, j = e - n * C0;
+      w0p[n * LDK + j] = P.param[w0_global(n * KP + j)];
+    }
+  }
 #pragma unroll
-  for (int u = 0; u < G0; ++u) {
+  for (int u = 0; u < (WIDE ? 0 : G0); ++u) {
     float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
     int at[4];
     group_at(u, at);
@@ -374,10 +400,14 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     }
     m0[u] = (v4f){m[0], m[1], m[2], m[3]}; v0[u] = (v4f){v[0], v[1], v[2], v[3]};
   }
-  bool own0[T1];      // accumulator tiles w + NW u of dW0' [H1][KP]
-  v4f acc0[T1];
+  bool own0[T1];      // accumulator tiles of dW0' [H1][KP]: rows 16 (w + NW u), columns 16 c
+  v4f acc0[T1][CT];
 #pragma unroll
-  for (int u = 0; u < T1; ++u) { own0[u] = w + NW * u < H1 / 16; acc0[u] = (v4f){0, 0, 0, 0}; }
+  for (int u = 0; u < T1; ++u) {
+    own0[u] = w + NW * u < H1 / 16;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc0[u][c] = (v4f){0, 0, 0, 0};
+  }
   // the small vectors: last layer [O][HL], its bias [O], hidden bias b1 [H2] (two hidden layers), log_std [O] (actor)
   auto vp_global = [&](int e) -> int64_t {
     if (e < L.o_b1) return N.w_off[D3 ? 2 : 1] + e;
@@ -557,17 +587,22 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
 #pragma unroll
             for (int u = 0; u < NTW; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq, wq[u], c[u], 0, 0, 0);
           } else {
-            const v4f xa = *(const v4f *)(X + (f_s0 + i) * LDK + 4 * q);
-            v4f wb[NTW];
+            v4f xa[CT], wb[NTW][CT];
 #pragma unroll
-            for (int u = 0; u < NTW; ++u) wb[u] = *(const v4f *)(w0p + (n0[u] + i) * LDK + 4 * q);
+            for (int kc = 0; kc < CT; ++kc) {
+              xa[kc] = *(const v4f *)(X + (f_s0 + i) * LDK + 16 * kc + 4 * q);
 #pragma unroll
-            for (int u = 0; u < NTW; ++u) {
-              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb[u].x, c[u], 0, 0, 0);
-              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb[u].y, c[u], 0, 0, 0);
-              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb[u].z, c[u], 0, 0, 0);
-              c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb[u].w, c[u], 0, 0, 0);
+              for (int u = 0; u < NTW; ++u) wb[u][kc] = *(const v4f *)(w0p + (n0[u] + i) * LDK + 16 * kc + 4 * q);
             }
+#pragma unroll
+            for (int kc = 0; kc < CT; ++kc)
+#pragma unroll
+              for (int u = 0; u < NTW; ++u) {
+                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].x, wb[u][kc].x, c[u], 0, 0, 0);
+                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].y, wb[u][kc].y, c[u], 0, 0, 0);
+                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].z, wb[u][kc].z, c[u], 0, 0, 0);
+                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].w, wb[u][kc].w, c[u], 0, 0, 0);
+              }
           }
 #pragma unroll
           for (int u = 0; u < NTW; ++u) {
@@ -590,7 +625,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         if (D3 || ntl <= 2 * NW) {
           tiles(std::integral_constant<int, 2>(), 0);
         } else {
-          constexpr int CH = O <= 2 ? 4 : 2;      // (three or four outputs: their partial dots take the registers)
+          constexpr int CH = (O <= 2 && !WIDE) ? 4 : 2;      // (three and more outputs: their partial dots take the registers)
           for (int u0 = 0; w + NW * u0 < ntl; u0 += CH) tiles(std::integral_constant<int, CH>(), u0);
         }
         if (!D3 && w < ntl) {
@@ -645,6 +680,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           out[o] = sacc;
         }
         if (role == 0) {      // critic: mse_loss(values, returns), weight alpha
+          if (TILES && P.adv_out && ok) P.adv_out[base + (int64_t)t * S + lane] = cur_ret - out[0];
           const float dv = out[0] - cur_ret;
           const float g = ok ? P.alpha * ((2.0f * invB) * dv) : 0.f;
           a_crit += ok ? dv * dv : 0.f;
@@ -761,7 +797,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         if (D3 || ns == 8) {
           pass(std::integral_constant<int, 2>(), gp_sr * ns);
         } else {
-          constexpr int CH = O <= 2 ? 4 : 2;
+          constexpr int CH = O <= 2 ? 4 : (O <= 4 ? 2 : 1);
           for (int c0 = 0; c0 < ns; c0 += 4 * CH) pass(std::integral_constant<int, CH>(), gp_sr * ns + c0);
         }
       }
@@ -794,12 +830,17 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       }
       STAMP(6);
       // ---- dW0'[n][j] += sum_s g1[n][s] x'[j][s]
-      if (T1 == 2 && own0[T1 - 1]) {
-        mma2<LS, LS>(g1t + w * 16 * LS, g1t + (w + NW) * 16 * LS, XT, XT, S, acc0[0], acc0[T1 - 1], i, q);
+      if (WIDE) {      // a row tile's two column tiles share its operand
+#pragma unroll
+        for (int u = 0; u < T1; ++u)
+          if (own0[u])
+            mma2<LS, LS>(g1t + (w + NW * u) * 16 * LS, g1t + (w + NW * u) * 16 * LS, XT, XT + 16 * LS, S, acc0[u][0], acc0[u][CT - 1], i, q);
+      } else if (T1 == 2 && own0[T1 - 1]) {
+        mma2<LS, LS>(g1t + w * 16 * LS, g1t + (w + NW) * 16 * LS, XT, XT, S, acc0[0][0], acc0[T1 - 1][0], i, q);
       } else {
 #pragma unroll
         for (int u = 0; u < T1; ++u)
-          if (own0[u]) acc0[u] = mma<LS, LS>(g1t + (w + NW * u) * 16 * LS, XT, S, acc0[u], i, q);
+          if (own0[u]) acc0[u][0] = mma<LS, LS>(g1t + (w + NW * u) * 16 * LS, XT, S, acc0[u][0], i, q);
       }
       STAMP(7);
       // the next tile's x' images are in the other buffers (stored at the top of this tile); its loss inputs become current
@@ -821,10 +862,10 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     // product that reads those.)
 #pragma unroll
     for (int u = 0; u < T1; ++u) {
-      if (own0[u]) {
+      if (own0[u] && !WIDE) {      // (the wide form writes the accumulators to the partial buffer itself, below)
         float *gp = gw0 + ((w + NW * u) * 16 + 4 * q) * LDK + i;
-        gp[0] = acc0[u].x; gp[LDK] = acc0[u].y; gp[2 * LDK] = acc0[u].z; gp[3 * LDK] = acc0[u].w;
-        acc0[u] = (v4f){0, 0, 0, 0};
+        gp[0] = acc0[u][0].x; gp[LDK] = acc0[u][0].y; gp[2 * LDK] = acc0[u][0].z; gp[3 * LDK] = acc0[u][0].w;
+        acc0[u][0] = (v4f){0, 0, 0, 0};
       }
     }
     if (gp_on) {
@@ -880,12 +921,26 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         }
         gp[vp_global(e)] = g;
       }
+      if (WIDE) {
 #pragma unroll
-      for (int u = 0; u < U0; ++u) {
+        for (int u = 0; u < T1; ++u)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            if (!own0[u]) continue;
+            const float g[4] = {acc0[u][c].x, acc0[u][c].y, acc0[u][c].z, acc0[u][c].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int64_t go = w0_global(((w + NW * u) * 16 + 4 * q + r) * KP + 16 * c + i);
+              if (go >= 0) gp[go] = g[r];
+            }
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < (WIDE ? 0 : U0); ++u) {
         const int e = tid + u * NT;
         if (e < n0e) {
           const int64_t go = w0_global(e);
-          if (go >= 0) gp[go] = gw0[(e >> 4) * LDK + (e & 15)];
+          if (go >= 0) gp[go] = gw0[(e / KP) * LDK + (e % KP)];
         }
       }
 #pragma unroll
@@ -1089,11 +1144,11 @@ __global__ __launch_bounds__(NT) void k_ppo_epoch(const Args P) {
 
 // One big batch: workgroup (role = blockIdx.x, g = blockIdx.y) carries slab g of the rows through the same tile pipeline
 // and leaves its partial gradient sums; k_tiles_reduce adds the slabs in order and applies clip_grad_value_ + Adam.
-template <bool D3, int AO, int KIND = 0>
+template <bool D3, int AO, int KIND = 0, int KPT = 16>
 __global__ __launch_bounds__(NT) void k_ppo_tiles(const Args P) {
   extern __shared__ __align__(16) float lds[];
-  if (blockIdx.x == 0) epoch_body<0, D3, 1, true, KIND>(P, lds);
-  else epoch_body<1, D3, AO, true, KIND>(P, lds);
+  if (blockIdx.x + P.role_base == 0) epoch_body<0, D3, 1, true, KIND, KPT>(P, lds);
+  else epoch_body<1, D3, AO, true, KIND, KPT>(P, lds);
 }
 
 struct Segs {
@@ -1136,7 +1191,7 @@ __global__ void k_tiles_total(float *losses, float alpha, float beta) {
 
 constexpr int64_t MAX_LDS_BYTES = 160 * 1024;
 
-int fill_net(const char *fn, const char *name, const trl_mlp_desc *d, const trl_adam_args *adam, int O, Net &n) {
+int fill_net(const char *fn, const char *name, const trl_mlp_desc *d, const trl_adam_args *adam, int O, Net &n, int kp = KP) {
   TRL_REQUIRE(d != nullptr, "%s: %s is NULL", fn, name);
   TRL_REQUIRE(d->depth == 2 || d->depth == 3, "%s: %s: depth 2 or 3 (one or two hidden layers), got %d", fn, name, d->depth);
   n.depth = d->depth;
@@ -1145,7 +1200,7 @@ int fill_net(const char *fn, const char *name, const trl_mlp_desc *d, const trl_
   n.H2 = d->depth == 3 ? d->dims[2] : 0;
   n.O = d->dims[d->depth];
   TRL_REQUIRE(n.O == O, "%s: %s: fan-out %d, expected %d", fn, name, n.O, O);
-  TRL_REQUIRE(n.d0 >= 1 && n.d0 <= KP - 1, "%s: %s: fan-in %d must be in [1, %d]", fn, name, n.d0, KP - 1);
+  TRL_REQUIRE(n.d0 >= 1 && n.d0 <= kp - 1, "%s: %s: fan-in %d must be in [1, %d]", fn, name, n.d0, kp - 1);
   TRL_REQUIRE(n.H1 >= 16 && n.H1 % 16 == 0 && n.H1 <= 256, "%s: %s: hidden width %d must be a multiple of 16 in [16, 256]", fn,
               name, n.H1);
   if (d->depth == 3) {
@@ -1176,6 +1231,26 @@ EpochKernel pick_kernel(bool d3, int A) {
   }
 }
 
+EpochKernel pick_tiles_kernel_wide(int kind, int A) {
+  if (kind == 1) {
+    switch (A) {
+      case 2: return k_ppo_tiles<false, 2, 1, KPW>;
+      case 3: return k_ppo_tiles<false, 3, 1, KPW>;
+      case 4: return k_ppo_tiles<false, 4, 1, KPW>;
+      case 5: return k_ppo_tiles<false, 5, 1, KPW>;
+      default: return k_ppo_tiles<false, 6, 1, KPW>;
+    }
+  }
+  switch (A) {
+    case 1: return k_ppo_tiles<false, 1, 0, KPW>;
+    case 2: return k_ppo_tiles<false, 2, 0, KPW>;
+    case 3: return k_ppo_tiles<false, 3, 0, KPW>;
+    case 4: return k_ppo_tiles<false, 4, 0, KPW>;
+    case 5: return k_ppo_tiles<false, 5, 0, KPW>;
+    default: return k_ppo_tiles<false, 6, 0, KPW>;
+  }
+}
+
 EpochKernel pick_tiles_kernel_a2c(bool d3, int A) {
   switch (A) {
     case 2: return d3 ? k_ppo_tiles<true, 2, 1> : k_ppo_tiles<false, 2, 1>;
@@ -1193,11 +1268,12 @@ EpochKernel pick_tiles_kernel(bool d3, int A) {
   }
 }
 
-// slabs of a batch of n rows: whole 64-row tiles, at most MAX_SLABS of them
+// slabs of a batch of n rows: whole 64-row tiles, at most MAX_SLABS of them (two workgroups a slab: one per CU), or twice
+// that when the roles are launched one after the other
 constexpr int MAX_SLABS = 128;
-void slab_plan(int64_t n, int64_t *slab, int *G) {
+void slab_plan(int64_t n, int64_t *slab, int *G, int max_slabs = MAX_SLABS) {
   const int64_t tiles = (n + S - 1) / S;
-  const int64_t per = (tiles + MAX_SLABS - 1) / MAX_SLABS;
+  const int64_t per = (tiles + max_slabs - 1) / max_slabs;
   *slab = per * S;
   *G = (int)((n + *slab - 1) / *slab);
 }
@@ -1334,12 +1410,13 @@ extern "C" int trl_ppo_learn_epoch(const trl_mlp_desc *critic, const trl_mlp_des
 
 // ---- one learn() step over ONE batch of any size through the same tile pipeline, spread over the chip: the general
 // whole-step path for the shapes trl_ppo_learn_epoch takes (fan-in <= 15, up to four actions, one hidden layer up to 256
-// wide or two up to 64) -- some of which trl_ppo_learn_fused's register-chained kernels do not
+// wide or two up to 64) -- some of which trl_ppo_learn_fused's register-chained kernels do not -- and, with ONE hidden
+// layer, for fan-in up to 31 and up to six actions (the wide form: ActorCriticNet(17, 6, 256))
 extern "C" int64_t trl_ppo_learn_tiles_workspace_bytes(int64_t n_flat, int64_t B) {
   if (n_flat <= 0 || B <= 0) return 0;
   int64_t slab; int G;
-  slab_plan(B, &slab, &G);
-  return ((int64_t)G * n_flat + 2 * (int64_t)G * 4 + 64) * (int64_t)sizeof(float);
+  slab_plan(B, &slab, &G, 2 * MAX_SLABS);      // (the larger of the two plans) + the advantage column of trl_a2c_learn_tiles
+  return ((int64_t)G * n_flat + 2 * (int64_t)G * 4 + 64 + (B + 63) / 64 * 64) * (int64_t)sizeof(float);
 }
 
 namespace {
@@ -1351,14 +1428,26 @@ int learn_tiles_impl(const char *fn, int kind, const trl_mlp_desc *critic, const
   TRL_REQUIRE(adam && adam->param && adam->grad && adam->n > 0, "%s: the optimizer block (flat buffers) is required", fn);
   TRL_REQUIRE(!update || (adam->exp_avg && adam->exp_avg_sq && adam->step >= 1 && !adam->dev_state),
               "%s: update needs the moment buffers and a host step count >= 1", fn);
-  TRL_REQUIRE(A >= (kind == 1 ? 2 : 1) && A <= MAXO, "%s: action size %d must be in [%d, %d]", fn, A, kind == 1 ? 2 : 1, MAXO);
+  TRL_REQUIRE(A >= (kind == 1 ? 2 : 1) && A <= MAXO_T, "%s: action size %d must be in [%d, %d]", fn, A, kind == 1 ? 2 : 1, MAXO_T);
+  TRL_REQUIRE(critic && actor, "%s: NULL network", fn);
+  // the wide form (32 columns at layer 0, up to six outputs) for what the 16-column kernels do not take; one hidden layer only
+  const bool wide = A > MAXO || critic->dims[0] > KP - 1;
+  TRL_REQUIRE(!wide || (critic->depth == 2 && actor->depth == 2),
+              "%s: more than %d observations or %d actions need networks of ONE hidden layer (got depth %d)", fn, KP - 1, MAXO,
+              critic->depth);
+  const int kp = wide ? KPW : KP;
   TRL_REQUIRE(B >= 1 && B <= (1ll << 31) - 64, "%s: bad batch size", fn);
-  TRL_REQUIRE(obs && action && returns && adv && losses_out && ws, "%s: NULL argument", fn);
-  TRL_REQUIRE(kind == 1 || (old_logp && log_std), "%s: NULL argument", fn);
+  TRL_REQUIRE(obs && action && returns && losses_out && ws, "%s: NULL argument", fn);
+  TRL_REQUIRE(kind == 1 ? true : (adv && old_logp && log_std), "%s: NULL argument", fn);
+  // One role per launch, each over twice the slabs: needed when the critic's launch is to compute the advantage for the
+  // actor's (A2C, adv == NULL), and faster for any big batch -- the actor's workgroups (A outputs) take longer than the
+  // critic's (one), so in one launch of both half the chip waits for the other half
+  const bool own_adv = kind == 1 && adv == nullptr;
+  const bool split = own_adv || B >= 4 * MAX_SLABS * S;
   TRL_REQUIRE(((uintptr_t)ws & 15) == 0, "%s: the workspace must be 16 B aligned", fn);
   Args P = {};
   int rc;
-  if ((rc = fill_net(fn, "critic", critic, adam, 1, P.net[0])) || (rc = fill_net(fn, "actor", actor, adam, A, P.net[1])))
+  if ((rc = fill_net(fn, "critic", critic, adam, 1, P.net[0], kp)) || (rc = fill_net(fn, "actor", actor, adam, A, P.net[1], kp)))
     return rc;
   TRL_REQUIRE(P.net[0].d0 == P.net[1].d0 && P.net[0].depth == P.net[1].depth,
               "%s: critic and actor must have the same fan-in and depth", fn);
@@ -1367,13 +1456,13 @@ int learn_tiles_impl(const char *fn, int kind, const trl_mlp_desc *critic, const
   P.net[1].ls_off = lo;
   int64_t lds_bytes = 0;
   for (int r = 0; r < 2; ++r) {
-    const int64_t b = (int64_t)make_lay(P.net[r]).total * 4;
+    const int64_t b = (int64_t)make_lay(P.net[r], kp).total * 4;
     lds_bytes = b > lds_bytes ? b : lds_bytes;
   }
   TRL_REQUIRE(lds_bytes <= MAX_LDS_BYTES, "%s: networks of this size need %lld B of LDS (limit %lld)", fn,
               (long long)lds_bytes, (long long)MAX_LDS_BYTES);
   int G;
-  slab_plan(B, &P.slab, &G);
+  slab_plan(B, &P.slab, &G, split ? 2 * MAX_SLABS : MAX_SLABS);
   P.param = adam->param; P.grad = adam->grad; P.m = adam->exp_avg; P.v = adam->exp_avg_sq;
   P.obs = obs; P.action = action; P.returns = returns; P.old_logp = old_logp; P.adv = adv;
   P.n_rows = B; P.B = 0; P.n_epochs = 1; P.A = A;
@@ -1383,15 +1472,26 @@ int learn_tiles_impl(const char *fn, int kind, const trl_mlp_desc *critic, const
   P.gpart = (float *)ws;
   P.lpart = P.gpart + (size_t)G * adam->n;
   P.losses = losses_out;
+  float *adv_ws = P.lpart + ((size_t)2 * G * 4 + 63) / 64 * 64;
   hipStream_t st = (hipStream_t)stream;
-  EpochKernel kern = kind == 1 ? pick_tiles_kernel_a2c(P.net[0].depth == 3, A) : pick_tiles_kernel(P.net[0].depth == 3, A);
+  EpochKernel kern = wide ? pick_tiles_kernel_wide(kind, A)
+                          : (kind == 1 ? pick_tiles_kernel_a2c(P.net[0].depth == 3, A) : pick_tiles_kernel(P.net[0].depth == 3, A));
   if (lds_bytes > 48 * 1024 &&
       hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess) {
     (void)hipGetLastError();
     trl_set_error("%s: could not raise the kernel's LDS limit", fn);
     return TRL_EHIP;
   }
-  hipLaunchKernelGGL(kern, dim3(2, G), dim3(NT), (size_t)lds_bytes, st, P);
+  if (split) {
+    P.adv_out = own_adv ? adv_ws : nullptr;
+    hipLaunchKernelGGL(kern, dim3(1, G), dim3(NT), (size_t)lds_bytes, st, P);      // the critic's workgroups
+    TRL_CHECK_LAUNCH(fn);
+    P.adv_out = nullptr; P.role_base = 1;
+    if (own_adv) P.adv = adv_ws;
+    hipLaunchKernelGGL(kern, dim3(1, G), dim3(NT), (size_t)lds_bytes, st, P);      // the actor's
+  } else {
+    hipLaunchKernelGGL(kern, dim3(2, G), dim3(NT), (size_t)lds_bytes, st, P);
+  }
   TRL_CHECK_LAUNCH(fn);
   // the parameters' places in the flat buffers, as segments: both networks' layers and log_std
   Segs sg = {};

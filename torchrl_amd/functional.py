@@ -941,15 +941,17 @@ class FusedPpoLearn:
   @staticmethod
   def tiles_supports(critic_lin, actor_lin, a2c=False):
     """Shapes the tile pipeline takes for one step over a batch of any size (trl_ppo_learn_tiles / trl_a2c_learn_tiles):
-    one hidden layer (a multiple of 16, <= 256) or two (<= 64) over at most 15 observations, up to four actions
-    (A2C: at least two), float32 parameters on a HIP device."""
+    one hidden layer (a multiple of 16, <= 256) over at most 31 observations with up to six actions, or two hidden
+    layers (<= 64) over at most 15 observations with up to four (A2C: at least two actions), float32 parameters on a
+    HIP device."""
     if len(critic_lin) != len(actor_lin) or len(critic_lin) not in (2, 3):
       return False
+    one = len(critic_lin) == 2
     A = actor_lin[-1].out_features
-    if critic_lin[-1].out_features != 1 or not (2 if a2c else 1) <= A <= 4:
+    if critic_lin[-1].out_features != 1 or not (2 if a2c else 1) <= A <= (6 if one else 4):
       return False
     K0 = critic_lin[0].in_features
-    if K0 != actor_lin[0].in_features or K0 > 15:
+    if K0 != actor_lin[0].in_features or K0 > (31 if one else 15):
       return False
     for lin in (critic_lin, actor_lin):
       hid = [m.out_features for m in lin[:-1]]
@@ -961,9 +963,9 @@ class FusedPpoLearn:
 
   def a2c_tiles(self, obs, action, returns, alpha, beta, adam, update=True):
     """A2CController.learn's device work through the tile pipeline (trl_a2c_learn_tiles) for the A2CNet shapes the
-    register-chained kernels do not take (three or four actions, a wide layer over 10 - 15 observations): the detached
-    advantage returns - V comes from the forward-only kernel where it takes the shape, else from the critic module.
-    Returns the [4] loss tensor."""
+    register-chained kernels do not take (three to six actions, a wide layer over 10 - 31 observations): the detached
+    advantage returns - V comes from the forward-only kernel where it takes the shape, else from the critic's own
+    workgroups of the step (launched ahead of the actor's).  Returns the [4] loss tensor."""
     C = self._C
     B = obs.shape[0]
     obs = _f32c(obs, 'obs')
@@ -973,17 +975,10 @@ class FusedPpoLearn:
       raise ValueError('a2c_learn_tiles: inconsistent shapes')
     if self._ptr_key() != self._key:
       self._bind()
-    with torch.no_grad():
-      if self.K0 <= 9 or (len(self.critic_lin) == 3 and self.K0 <= 12):
-        value = self.forward(obs, want_mean=False)[0]
-      else:
-        h = obs
-        for i, m in enumerate(self.critic_lin):
-          h = torch.nn.functional.linear(h, m.weight, m.bias)
-          if i + 1 < len(self.critic_lin):
-            h = torch.relu(h)
-        value = h.view(-1)
-      adv = (returns.view(-1) - value).contiguous()
+    adv = None      # (the library's own: the critic's workgroups run first and leave returns - V for the actor's)
+    if self.K0 <= 9 or (len(self.critic_lin) == 3 and self.K0 <= 12):
+      with torch.no_grad():      # the forward-only kernel takes the shape: both roles in one launch behind it
+        adv = (returns.view(-1) - self.forward(obs, want_mean=False)[0]).contiguous()
     dev = obs.device
     lib = _lib.lib()
     a = adam.fused_args(update)
@@ -992,7 +987,8 @@ class FusedPpoLearn:
     with torch.cuda.device(dev):
       _lib.check(lib.trl_a2c_learn_tiles(
           C.byref(self.descs[0]), C.byref(self.descs[1]), obs.data_ptr(), action.data_ptr(), returns.data_ptr(),
-          adv.data_ptr(), B, self.A, float(alpha), float(beta), losses.data_ptr(), C.byref(a), 1 if update else 0,
+          adv.data_ptr() if adv is not None else None, B, self.A, float(alpha), float(beta), losses.data_ptr(), C.byref(a),
+          1 if update else 0,
           ws.data_ptr(), _lib.stream_ptr(dev)))
     return losses
 
