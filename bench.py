@@ -698,6 +698,42 @@ def bench_a2c(args, rank, world, dev):
   }
   return res, {}
 
+# ------------------------------------------------------------------------------ nets outside the register-chained kernels
+def wide_nets(dev, B=1 << 20):
+  """One learn() over a 1 M-row batch on the reference's default width (256) with more observations / actions than the
+  whole-step kernels of csrc/trl_learn.hip take: the tile pipeline spread over the chip (csrc/trl_epoch.hip:
+  trl_ppo_learn_tiles / trl_a2c_learn_tiles) against the layer-by-layer path (fused=False) of the same controller."""
+  rows = []
+  for kind, obs_size, A in (('ppo', 8, 4), ('ppo', 17, 6), ('a2c', 8, 4), ('a2c', 17, 6)):
+    g = torch.Generator(device=dev).manual_seed(obs_size + A)
+    o = torch.randn(B, obs_size, device=dev, generator=g)
+    r = torch.randn(B, 1, device=dev, generator=g)
+    row = {'net': '%s(%d, %d, 256)' % ('ActorCriticNet' if kind == 'ppo' else 'A2CNet', obs_size, A), 'rows': B}
+    for fused in (True, False):
+      if kind == 'ppo':
+        c = PPOController(obs_size, A, device=dev, hidden=(256,), fused=fused)
+        a, l, ad = (torch.randn(B, A, device=dev, generator=g), torch.randn(B, A, device=dev, generator=g) - 1,
+                    torch.randn(B, 1, device=dev, generator=g))
+        fn = lambda: c.learn(o, a, None, None, None, r, l, ad)  # noqa: E731
+      else:
+        c = A2CController(obs_size, A, device=dev, hidden=(256,), fused=fused)
+        a = torch.randint(0, A, (B, 1), device=dev, generator=g).float()
+        fn = lambda: c.learn(o, a, None, None, None, r)  # noqa: E731
+      for _ in range(2):
+        fn()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(5):
+        fn()
+      torch.cuda.synchronize()
+      key = 'ms_learn_tiles' if fused and getattr(c, '_tiles', None) is not None and c._fused is None else \
+          ('ms_learn' if fused else 'ms_learn_layer_path')
+      row[key] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+      del c
+    rows.append(row)
+  return rows
+
+
 # ------------------------------------------------------------------------------ replay gathers
 def fill_ring(ds, n_rows, make_cols, chunk):
   for lo in range(0, n_rows, chunk):
@@ -986,6 +1022,11 @@ def main(argv=None):
                                          if k in r2})
         except Exception as e:  # noqa: BLE001  (an extra must not take the headline line down)
           res['other_workloads'].append({'workload': wl, 'error': str(e)[:300]})
+      torch.cuda.empty_cache()
+      try:
+        res['wide_nets'] = wide_nets(dev)
+      except Exception as e:  # noqa: BLE001
+        res['wide_nets'] = {'error': str(e)[:300]}
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_base if cpu_base is not None else cpu_baseline_offpolicy(info)
   if dist.is_initialized():
