@@ -26,9 +26,12 @@ def timed(fn):
   return (time.perf_counter() - t) / 10 * 1e3, {k: round(float(v), 5) for k, v in info.items()}
 
 
-for kind, obs, A, hid in (('ppo', 8, 4, (256,)), ('ppo', 15, 4, (256,)), ('ppo', 12, 3, (256,)), ('ppo', 8, 4, (128,)),
-                          ('ppo', 17, 6, (256,)), ('ppo', 24, 4, (256,)), ('ppo', 31, 6, (256,)), ('ppo', 17, 6, (64,)),
-                          ('a2c', 8, 4, (256,)), ('a2c', 17, 6, (256,)), ('a2c', 31, 6, (256,))):
+CASES = (('ppo', 8, 4, (256,)), ('ppo', 15, 4, (256,)), ('ppo', 12, 3, (256,)), ('ppo', 8, 4, (128,)),
+          ('ppo', 17, 6, (256,)), ('ppo', 24, 4, (256,)), ('ppo', 31, 6, (256,)), ('ppo', 17, 6, (64,)),
+                          ('a2c', 8, 4, (256,)), ('a2c', 17, 6, (256,)), ('a2c', 31, 6, (256,)))
+if len(sys.argv) >= 5:      # one shape: kind obs actions hidden   (e.g. under rocprofv3 --kernel-trace --stats)
+  CASES = ((sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), tuple(int(h) for h in sys.argv[4].split(','))),)
+for kind, obs, A, hid in CASES:
   o = torch.randn(B, obs, device=dev)
   r = torch.randn(B, 1, device=dev)
   line = '%s obs %2d actions %d hidden %s:' % (kind, obs, A, hid)

@@ -797,7 +797,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         if (D3 || ns == 8) {
           pass(std::integral_constant<int, 2>(), gp_sr * ns);
         } else {
-          constexpr int CH = O <= 2 ? 4 : (O <= 4 ? 2 : 1);
+          constexpr int CH = O <= 2 ? 4 : 2;
           for (int c0 = 0; c0 < ns; c0 += 4 * CH) pass(std::integral_constant<int, CH>(), gp_sr * ns + c0);
         }
       }
