@@ -31,7 +31,7 @@ class A2CController(Controller):
       if F.FusedPpoLearn.supports(lins[0], lins[1], None):
         self._fused = F.FusedPpoLearn(lins[0], lins[1], None, products=products or config.learn_products)
       elif F.FusedPpoLearn.tiles_supports(lins[0], lins[1], a2c=True):
-        # shapes outside the register-chained kernels (three or four actions, a wide layer over 10..15 observations):
+        # shapes outside the register-chained kernels (three to six actions, a wide layer over 10..31 observations):
         # the tile pipeline spread over the chip (trl_a2c_learn_tiles, csrc/trl_epoch.hip)
         self._tiles = F.FusedPpoLearn(lins[0], lins[1], None)
     self._run = LearnRunner(self._learn_body, [self.ac_net_optim], lambda: [], self.device, graph)
