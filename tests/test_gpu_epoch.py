@@ -295,3 +295,68 @@ def test_a2c_learn_tiles_matches_oracle(obs_size, A, hidden, B):
   got_w = ctl._flat.dense().cpu()
   assert float((got_w - exp_w).abs().max()) <= 2.5e-3
   assert float(((got_w - exp_w).abs() > 1e-5).float().mean()) < 0.02
+
+
+# ---------------------------------------------------------------- ragged tiny batches and refusals, through the C ABI entry itself
+@pytest.mark.parametrize('obs_size,A,hidden', [(8, 4, (128,)), (17, 6, (256,)), (20, 5, (48,))])
+@pytest.mark.parametrize('B', [1, 31, 65])
+def test_learn_tiles_tiny_ragged_batches(obs_size, A, hidden, B):
+  """One row, less than a tile, a tile and one row: the controller sends such batches down the layer path
+  (TILES_MIN_BATCH), the entry itself takes any B >= 1 -- gradients only, against autograd on the oracle's loss."""
+  ctl = _make(obs_size, A, hidden, 3 * B + A)
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  obs, act, ret, old, adv = _data(obs_size, A, B, 11 + B, ref)
+  ref_opt = torch.optim.SGD(ref.parameters(), lr=0.0)        # (no update: the gradients are what is compared)
+  exp = loss_oracle.ppo_learn(ref, ref_opt, obs, act, None, None, None, ret, old, adv, clip=0.2, alpha=0.5, beta=1e-2,
+                              max_grad_norm=1e9)
+  exp_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+  c = _cols(obs, act, ret, old, adv)
+  l4 = ctl._tiles.learn_tiles(c[0], c[1], c[5], c[6], c[7], 0.2, 0.5, 1e-2, ctl.ac_net_optim, update=False)
+  torch.cuda.synchronize()
+  for i, k in enumerate(('actor_loss', 'critic_loss', 'entropy_loss')):
+    e, v = float(exp[k]), float(l4[i].cpu())
+    assert abs(v - e) <= 1e-6 * abs(e) + 2e-7, (k, v, e)
+  got = ctl._flat.dense(grad=True).cpu()
+  np.testing.assert_allclose(got.numpy(), exp_grad.numpy(), rtol=1e-4, atol=2e-5 * float(exp_grad.abs().max()))
+
+
+def test_learn_tiles_refuses_what_it_does_not_take():
+  """Two hidden layers stop at 15 observations / four actions, one hidden layer at 31 / six; the entry says so
+  (TRL_EINVAL with a message) instead of computing something else."""
+  from torchrl_amd import functional as F
+  for obs_size, A, hidden in ((17, 2, (64, 64)), (3, 5, (64, 64)), (32, 2, (64,)), (4, 7, (64,))):
+    ctl = _make(obs_size, A, hidden, 1)
+    assert ctl._tiles is None
+    lins = [[m for m in st if isinstance(m, torch.nn.Linear)] for st in (ctl.ac_net.critic, ctl.ac_net.actor)]
+    f = ctl._fused if ctl._fused is not None else F.FusedPpoLearn(lins[0], lins[1], ctl.ac_net.log_std)
+    obs, act, ret, old, adv = _data(obs_size, A, 64, 2, copy.deepcopy(ctl.ac_net).cpu())
+    c = _cols(obs, act, ret, old, adv)
+    with pytest.raises(Exception) as ei:
+      f.learn_tiles(c[0], c[1], c[5], c[6], c[7], 0.2, 0.5, 1e-2, ctl.ac_net_optim, update=False)
+    assert 'trl_ppo_learn_tiles' in str(ei.value)
+
+
+@pytest.mark.parametrize('obs_size,A,hidden', [(8, 4, (256,)), (17, 6, (256,))])
+@pytest.mark.parametrize('B', [1, 33, 130])
+def test_a2c_learn_tiles_tiny_ragged_batches(obs_size, A, hidden, B):
+  """As above for trl_a2c_learn_tiles, both ways of getting the advantage (8 observations: the forward-only kernel and one
+  launch of both kinds of workgroup; 17: the critic's own workgroups, launched first)."""
+  from torchrl_amd.contrib.controllers import A2CController
+  torch.manual_seed(5 * B + A)
+  ctl = A2CController(obs_size, A, lr=1e-3, alpha=0.5, beta=1e-2, device=DEV, hidden=hidden)
+  assert ctl._fused is None and ctl._tiles is not None
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  ref_opt = torch.optim.SGD(ref.parameters(), lr=0.0)
+  g = torch.Generator().manual_seed(B)
+  obs = torch.randn(B, obs_size, generator=g)
+  act = torch.randint(0, A, (B, 1), generator=g).float()
+  ret = torch.randn(B, 1, generator=g)
+  exp = loss_oracle.a2c_learn(ref, ref_opt, obs, act, None, None, None, ret, alpha=0.5, beta=1e-2)
+  exp_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+  l4 = ctl._tiles.a2c_tiles(obs.to(DEV), act.to(DEV), ret.to(DEV), 0.5, 1e-2, ctl.ac_net_optim, update=False)
+  torch.cuda.synchronize()
+  for i, k in enumerate(('actor_loss', 'critic_loss', 'entropy_loss')):
+    e, v = float(exp[k]), float(l4[i].cpu())
+    assert abs(v - e) <= 2e-6 * abs(e) + 2e-7, (k, v, e)
+  got = ctl._flat.dense(grad=True).cpu()
+  np.testing.assert_allclose(got.numpy(), exp_grad.numpy(), rtol=1e-4, atol=2e-5 * float(exp_grad.abs().max()))
