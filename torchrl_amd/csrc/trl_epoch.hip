@@ -276,9 +276,15 @@ __device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, co
 #ifdef TRL_TUNING      // diagnostic build: clock stamps of every wave at the phase boundaries of an update (tools/epoch_stamps.py); taken at
                        // every update of the launch's second half so that the stamp code itself is warm, update K - 2's survive
 __device__ unsigned long long g_epoch_stamp[2][8][16];
+// (tiles mode: slab 0's middle tile, stamps 0 .. 8, and the next tile's start as stamp 9: tools/tiles_stamps.py)
 #define STAMP(j)                                                                                              \
   do {                                                                                                        \
-    if (lane == 0 && k >= K / 2 && k + 1 < K && t == 0) g_epoch_stamp[role][w][j] = __builtin_amdgcn_s_memtime(); \
+    if (TILES) {                                                                                              \
+      if (lane == 0 && blockIdx.y == 0 && (j) <= 8 && t == ntile / 2) g_epoch_stamp[role][w][j] = __builtin_amdgcn_s_memtime(); \
+      if (lane == 0 && blockIdx.y == 0 && (j) == 0 && t == ntile / 2 + 1) g_epoch_stamp[role][w][9] = __builtin_amdgcn_s_memtime(); \
+    } else if (lane == 0 && k >= K / 2 && k + 1 < K && t == 0) {                                              \
+      g_epoch_stamp[role][w][j] = __builtin_amdgcn_s_memtime();                                               \
+    }                                                                                                         \
   } while (0)
 #else
 #define STAMP(j) \
@@ -356,8 +362,17 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   // with all four lanes of the vector at work, and the groups of a small layer fall on the first waves only.
   const int n0e = H1 * KP;
   const int C0 = d0 + 1, n0v = H1 * C0;
+  // Tiles mode keeps the columns of the layer-0 images PERMUTED within each block of 16: column j sits in slot
+  // 4 (j & 3) + ((j & 15) >> 2) (a 4 x 4 transpose: its own inverse).  The c-th MFMA of a k round multiplies slots
+  // {c, 4 + c, 8 + c, 12 + c}, so the real columns -- fan-in + bias, e.g. 9 of 16 or 18 of 32 -- fill the first
+  // ceil(columns / 4) MFMAs of a round and the forward pass skips the rest (all-zero products).  The persistent form
+  // keeps the natural order (its per-thread ownership walks consecutive columns).
+  constexpr bool PERM = TILES;
+  auto slot_of = [&](int j) { return PERM ? (j & ~15) + 4 * (j & 3) + ((j & 15) >> 2) : j; };
+  const int nck0 = C0 >= 16 ? 4 : (C0 + 3) / 4;                            // MFMAs of the first k round
+  const int nck1 = C0 <= 16 ? 0 : (C0 >= 32 ? 4 : (C0 - 16 + 3) / 4);  // ... of the second
   auto w0_global = [&](int e) -> int64_t {
-    const int n = e / KP, j = e % KP;
+    const int n = e / KP, j = slot_of(e % KP);      // (slot -> column)
     return j < d0 ? N.w_off[0] + (int64_t)n * d0 + j : (j == d0 ? N.b_off[0] + n : -1);
   };
   v4f m0[G0], v0[G0];
@@ -379,14 +394,14 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   };
   for (int e = tid; e < H1 * LDK; e += NT) w0p[e] = 0.f;      // (the padding columns stay zero for good)
   __syncthreads();
-  if (WIDE) {
+  if (PERM) {
     for (int e = tid; e < n0v; e += NT) {
       const int n = e / C0, j = e - n * C0;
-      w0p[n * LDK + j] = P.param[w0_global(n * KP + j)];
+      w0p[n * LDK + slot_of(j)] = P.param[w0_global(n * KP + slot_of(j))];
     }
   }
 #pragma unroll
-  for (int u = 0; u < (WIDE ? 0 : G0); ++u) {
+  for (int u = 0; u < (PERM ? 0 : G0); ++u) {
     float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
     int at[4];
     group_at(u, at);
@@ -468,15 +483,15 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       const int e = tid + u * NT;
       if (e < S * d0) {
         const int s = e / d0, j = e - s * d0;
-        X[s * LDK + j] = xin[u];
-        XT[j * LS + s] = xin[u];
+        X[s * LDK + slot_of(j)] = xin[u];
+        XT[slot_of(j) * LS + s] = xin[u];
       }
     }
     for (int e = tid; e < (KP - d0) * S; e += NT) {
       const int s = e & 63, j = d0 + (e >> 6);
       const float v = (j == d0 && s < rows) ? 1.f : 0.f;
-      X[s * LDK + j] = v;
-      XT[j * LS + s] = v;
+      X[s * LDK + slot_of(j)] = v;
+      XT[slot_of(j) * LS + s] = v;
     }
   };
   auto tile_of = [&](int k, int t, int64_t &row0, int &rows, int &bm) {      // update k, tile t -> rows of the data
@@ -580,10 +595,10 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
             c[u] = (v4f){0, 0, 0, 0};
           }
           if (d0 < 4) {      // fan-in + bias fit one MFMA: k = q
-            const float xq = X[(f_s0 + i) * LDK + q];
+            const float xq = X[(f_s0 + i) * LDK + slot_of(q)];
             float wq[NTW];
 #pragma unroll
-            for (int u = 0; u < NTW; ++u) wq[u] = w0p[(n0[u] + i) * LDK + q];
+            for (int u = 0; u < NTW; ++u) wq[u] = w0p[(n0[u] + i) * LDK + slot_of(q)];
 #pragma unroll
             for (int u = 0; u < NTW; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq, wq[u], c[u], 0, 0, 0);
           } else {
@@ -595,14 +610,25 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
               for (int u = 0; u < NTW; ++u) wb[u][kc] = *(const v4f *)(w0p + (n0[u] + i) * LDK + 16 * kc + 4 * q);
             }
 #pragma unroll
-            for (int kc = 0; kc < CT; ++kc)
+            for (int kc = 0; kc < CT; ++kc) {
+              const int nc = PERM ? (kc == 0 ? nck0 : nck1) : 4;      // (wave-uniform)
+              if (nc > 0) {
 #pragma unroll
-              for (int u = 0; u < NTW; ++u) {
-                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].x, wb[u][kc].x, c[u], 0, 0, 0);
-                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].y, wb[u][kc].y, c[u], 0, 0, 0);
-                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].z, wb[u][kc].z, c[u], 0, 0, 0);
-                c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].w, wb[u][kc].w, c[u], 0, 0, 0);
+                for (int u = 0; u < NTW; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].x, wb[u][kc].x, c[u], 0, 0, 0);
               }
+              if (nc > 1) {
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].y, wb[u][kc].y, c[u], 0, 0, 0);
+              }
+              if (nc > 2) {
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].z, wb[u][kc].z, c[u], 0, 0, 0);
+              }
+              if (nc > 3) {
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kc].w, wb[u][kc].w, c[u], 0, 0, 0);
+              }
+            }
           }
 #pragma unroll
           for (int u = 0; u < NTW; ++u) {
@@ -833,8 +859,10 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       if (WIDE) {      // a row tile's two column tiles share its operand
 #pragma unroll
         for (int u = 0; u < T1; ++u)
-          if (own0[u])
-            mma2<LS, LS>(g1t + (w + NW * u) * 16 * LS, g1t + (w + NW * u) * 16 * LS, XT, XT + 16 * LS, S, acc0[u][0], acc0[u][CT - 1], i, q);
+          if (own0[u]) {
+            if (nck1 > 0) mma2<LS, LS>(g1t + (w + NW * u) * 16 * LS, g1t + (w + NW * u) * 16 * LS, XT, XT + 16 * LS, S, acc0[u][0], acc0[u][CT - 1], i, q);
+            else acc0[u][0] = mma<LS, LS>(g1t + (w + NW * u) * 16 * LS, XT, S, acc0[u][0], i, q);      // (five or six actions over <= 15 observations)
+          }
       } else if (T1 == 2 && own0[T1 - 1]) {
         mma2<LS, LS>(g1t + w * 16 * LS, g1t + (w + NW) * 16 * LS, XT, XT, S, acc0[0][0], acc0[T1 - 1][0], i, q);
       } else {
