@@ -449,9 +449,11 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
   float xin[XU];
 #pragma unroll
   for (int u = 0; u < XU; ++u) xin[u] = 0.f;
-  float in_act[O], in_old[O], in_adv = 0.f, in_ret = 0.f;
-#pragma unroll
-  for (int a = 0; a < O; ++a) in_act[a] = in_old[a] = 0.f;
+  // PPO's actor loss is independent per (sample, action dimension): wave a < O takes dimension a of the tile's 64 samples
+  // (the critic's and A2C's -- a softmax over the actions -- stay on wave 0), so the loss phase is one dimension long
+  constexpr bool LW = role == 1 && KIND == 0;
+  float in_act[1], in_old[1], in_adv = 0.f, in_ret = 0.f;
+  in_act[0] = in_old[0] = 0.f;
   auto prefetch = [&](int64_t row0, int rows) {
     row0 += base;
 #pragma unroll
@@ -459,7 +461,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       const int e = tid + u * NT;
       xin[u] = e < rows * d0 ? P.obs[row0 * d0 + e] : 0.f;
     }
-    if (w == 0) {
+    if (LW ? w < O : w == 0) {
       const bool ok = lane < rows;
       const int64_t r = row0 + (ok ? lane : 0);
       if (role == 0) {
@@ -468,9 +470,8 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         in_adv = ok ? P.adv[r] : 0.f;
         if (KIND == 1) {
           in_act[0] = ok ? P.action[r] : 0.f;      // the action's index
-        } else {
-#pragma unroll
-          for (int a = 0; a < O; ++a) { in_act[a] = ok ? P.action[r * O + a] : 0.f; in_old[a] = ok ? P.old_logp[r * O + a] : 0.f; }
+        } else {      // (LW: wave a carries action dimension a)
+          in_act[0] = ok ? P.action[r * O + w] : 0.f; in_old[0] = ok ? P.old_logp[r * O + w] : 0.f;
         }
       }
     }
@@ -519,10 +520,9 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     prefetch(row0, prow);
     store_x(lds + L.xp[0], lds + L.xpt[0], prow);
   }
-  float cur_act[O], cur_old[O], cur_adv = in_adv, cur_ret = in_ret;
-  float nxt_act[O], nxt_old[O], nxt_adv = 0.f, nxt_ret = 0.f;
-#pragma unroll
-  for (int a = 0; a < O; ++a) { cur_act[a] = in_act[a]; cur_old[a] = in_old[a]; nxt_act[a] = nxt_old[a] = 0.f; }
+  float cur_act[1], cur_old[1], cur_adv = in_adv, cur_ret = in_ret;
+  float nxt_act[1], nxt_old[1], nxt_adv = 0.f, nxt_ret = 0.f;
+  cur_act[0] = in_act[0]; cur_old[0] = in_old[0]; nxt_act[0] = nxt_old[0] = 0.f;
   advance(pk, pt);
   if (pk < K) {
     int64_t row0; int bm;
@@ -558,8 +558,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       if (more) {
         store_x(lds + (cur ? xp0 : xp1), lds + (cur ? xpt0 : xpt1), prow);
         nxt_adv = in_adv; nxt_ret = in_ret;
-#pragma unroll
-        for (int a = 0; a < O; ++a) { nxt_act[a] = in_act[a]; nxt_old[a] = in_old[a]; }
+        nxt_act[0] = in_act[0]; nxt_old[0] = in_old[0];
         advance(pk, pt);
         if (pk < K) {
           int64_t row0; int bm;
@@ -696,7 +695,38 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       }
       STAMP(2);
       // ---- loss and its derivative at the outputs (wave 0, lane = sample): k_ppo_loss's arithmetic
-      if (w == 0) {
+      if (LW) {
+        // PPO's actor: wave a < O, action dimension a of the tile's samples (k_ppo_loss's arithmetic)
+        if (w < O) {
+          const bool ok = lane < rows_t;
+          const int a = w;
+          float outa = vpp[L.o_bl + a];
+          for (int sl = 0; sl < L.nred; ++sl) outa += red[(sl * O + a) * LS + lane];
+          const float gmin = -(1.0f / (float)(nb * O));
+          const float sigma = expf(vpp[L.o_ls + a]);
+          const float var = sigma * sigma;
+          const float logsig = logf(sigma);
+          const float den = 2.0f * var;
+          const float d = cur_act[0] - outa;
+          const float sq = d * d;
+          const float lp = ((-sq) / den - logsig) - LOG_SQRT_2PI;
+          const float ratio = expf(lp - cur_old[0]);
+          const float s1 = ratio * cur_adv;
+          const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
+          const float s2 = rc * cur_adv;
+          const float g1 = s1 < s2 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+          const float g2v = s2 < s1 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
+          const bool inr = ratio >= P.lo && ratio <= P.hi;
+          const float g_ratio = g1 * cur_adv + (inr ? g2v * cur_adv : 0.f);
+          const float g_lp = g_ratio * ratio;
+          const float g = ok ? (g_lp / den) * (2.0f * d) : 0.f;
+          a_min += ok ? fminf(s1, s2) : 0.f;
+          a_ent += ok ? ENT_CONST + logsig : 0.f;
+          a_dls[0] += ok ? g_lp * (sq / var - 1.0f) : 0.f;
+          a_gb[0] += g;
+          gout[a * LS + lane] = g;
+        }
+      } else if (w == 0) {
         const bool ok = lane < rows_t;
         float out[O];
 #pragma unroll
@@ -751,33 +781,6 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           }
           a_min += ok ? cur_adv * logp : 0.f;
           a_ent += ok ? -ent : 0.f;
-        } else {
-          const float gmin = -(1.0f / (float)(nb * O));
-#pragma unroll
-          for (int a = 0; a < O; ++a) {
-            const float sigma = expf(vpp[L.o_ls + a]);
-            const float var = sigma * sigma;
-            const float logsig = logf(sigma);
-            const float den = 2.0f * var;
-            const float d = cur_act[a] - out[a];
-            const float sq = d * d;
-            const float lp = ((-sq) / den - logsig) - LOG_SQRT_2PI;
-            const float ratio = expf(lp - cur_old[a]);
-            const float s1 = ratio * cur_adv;
-            const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
-            const float s2 = rc * cur_adv;
-            const float g1 = s1 < s2 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
-            const float g2v = s2 < s1 ? gmin : (s1 == s2 ? 0.5f * gmin : 0.f);
-            const bool inr = ratio >= P.lo && ratio <= P.hi;
-            const float g_ratio = g1 * cur_adv + (inr ? g2v * cur_adv : 0.f);
-            const float g_lp = g_ratio * ratio;
-            const float g = ok ? (g_lp / den) * (2.0f * d) : 0.f;
-            a_min += ok ? fminf(s1, s2) : 0.f;
-            a_ent += ok ? ENT_CONST + logsig : 0.f;
-            a_dls[a] += ok ? g_lp * (sq / var - 1.0f) : 0.f;
-            a_gb[a] += g;
-            gout[a * LS + lane] = g;
-          }
         }
       }
       __syncthreads();
@@ -875,8 +878,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       if (more) {
         cur ^= 1;
         cur_adv = nxt_adv; cur_ret = nxt_ret;
-#pragma unroll
-        for (int a = 0; a < O; ++a) { cur_act[a] = nxt_act[a]; cur_old[a] = nxt_old[a]; }
+        cur_act[0] = nxt_act[0]; cur_old[0] = nxt_old[0];
       }
       STAMP(8);
       if (t + 1 < ntile) __syncthreads();
@@ -902,7 +904,21 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       if (D3) part[(gp_sr * L.PO + O) * L.HLP + gp_n] = db1;
     }
     float *lout = TILES ? P.lpart + ((size_t)role * gridDim.y + blockIdx.y) * 4 : P.losses + 4 * k;
-    if (w == 0) {
+    if (LW) {
+      // every loss wave's sums; wave 0 adds the dimensions' loss sums in order behind the barrier (`red` is free: the last
+      // tile's loss phase, which read it, is two barriers back)
+      if (w < O) {
+        const float s_min = trl_wave_sum(a_min), s_ent = trl_wave_sum(a_ent);
+        const float gb = trl_wave_sum(a_gb[0]), gl = trl_wave_sum(a_dls[0]);
+        // the entropy term's share of d loss / d log_std[a], d(-beta * mean(ent)) = -beta / A: once per batch
+        const float ent_share = (!TILES || blockIdx.y == 0) ? -P.beta / (float)O : 0.f;
+        if (lane == 0) {
+          red[w] = s_min; red[8 + w] = s_ent;
+          tailg[w] = gb;
+          tailg[L.o_ls - L.o_bl + w] = gl + ent_share;
+        }
+      }
+    } else if (w == 0) {
       if (role == 0) {
         const float s_crit = trl_wave_sum(a_crit), gb = trl_wave_sum(a_gb[0]);
         if (lane == 0) {
@@ -929,6 +945,13 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       }
     }
     __syncthreads();
+    if (LW && tid == 0) {
+      float s_min = 0.f, s_ent = 0.f;
+      for (int a = 0; a < O; ++a) { s_min += red[a]; s_ent += red[8 + a]; }
+      const float invBA = 1.0f / (float)(nb * O);
+      lout[0] = TILES ? s_min : -(s_min * invBA);
+      lout[2] = TILES ? s_ent : s_ent * invBA;
+    }
     STAMP(9);
     if (TILES) {
       // ---- partial sums of this slab -> the workgroup's plane of the partial buffer (the reduce launch adds the planes
