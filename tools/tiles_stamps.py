@@ -36,3 +36,7 @@ for role in range(2):
   print('  %-48s %s' % ('phase \\ wave', ' '.join('%6d' % w for w in range(8))))
   for j in range(9):
     print('  %-48s %s' % (names[j + 1], ' '.join('%6d' % (st[w][j + 1] - st[w][j]) for w in range(8))))
+  # inside the layer-0 phase: [10] behind the tiles' products and epilogues, [11] behind the row sums of the last layer's dots
+  sx = [[out[(role * 8 + w) * 16 + j] for j in (0, 10, 11, 1)] for w in range(8)]
+  for j, nm in enumerate(('  layer 0: tiles (products, relu, stores, dot FMAs)', '  layer 0: row sums of the dots -> LDS', '  layer 0: barrier')):
+    print('  %-48s %s' % (nm, ' '.join('%6d' % (sx[w][j + 1] - sx[w][j]) for w in range(8))))

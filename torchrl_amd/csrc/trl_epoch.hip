@@ -286,9 +286,17 @@ __device__ unsigned long long g_epoch_stamp[2][8][16];
       g_epoch_stamp[role][w][j] = __builtin_amdgcn_s_memtime();                                               \
     }                                                                                                         \
   } while (0)
+// (tiles mode, inside a phase: any stamp index)
+#define STAMPX(j)                                                                                             \
+  do {                                                                                                        \
+    if (TILES && lane == 0 && blockIdx.y == 0 && t == ntile / 2) g_epoch_stamp[role][w][j] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #else
 #define STAMP(j) \
   do {           \
+  } while (0)
+#define STAMPX(j) \
+  do {            \
   } while (0)
 #endif
 
@@ -653,6 +661,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           constexpr int CH = (O <= 2 && !WIDE) ? 4 : 2;      // (three and more outputs: their partial dots take the registers)
           for (int u0 = 0; w + NW * u0 < ntl; u0 += CH) tiles(std::integral_constant<int, CH>(), u0);
         }
+        STAMPX(10);
         if (!D3 && w < ntl) {
 #pragma unroll
           for (int o = 0; o < O; ++o) {
@@ -661,6 +670,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
             if (i == 0) *(v4f *)(red + ((w >> 2) * O + o) * LS + f_s0 + 4 * q) = sres;
           }
         }
+        STAMPX(11);
       }
       __syncthreads();
       STAMP(1);
