@@ -482,6 +482,15 @@ int trl_a2c_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, c
                         const float *returns, const float *adv, int64_t B, int32_t A, double alpha, double beta,
                         float *losses_out, const trl_adam_args *adam, int32_t update, void *ws, void *stream);
 
+/* The forward passes of compute_return (ppo_controller.py:32-51: values = critic(obs), dist = Normal(actor(obs),
+ * exp(log_std)), log_probs = dist.log_prob(action); a2c_controller.py:30: values) through the same tile pipeline, for
+ * the shapes trl_ppo_forward_fused does not take (those of trl_ppo_learn_tiles): the tiles stop behind the loss phase,
+ * whose waves write value_out [B], mean_out [B, A] (or NULL) and logp_out [B, A] (or NULL; needs `action` [B, A]).
+ * actor == NULL: the critic alone (A2CNet's values, the bootstrap values).  No workspace. */
+int trl_ac_forward_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std, const float *obs,
+                         const float *action, int64_t B, int32_t A, float *value_out, float *mean_out, float *logp_out,
+                         void *stream);
+
 /* ------------------------------------------------------------------ fused off-policy learner steps (a-2 + a-4)
  * DDPGController.learn (ddpg_controller.py:101-128) as 10 phases of one tile kernel (csrc/trl_offpolicy.hip;
  * one launch, or one per phase: trl_offpolicy_set_chain): the five

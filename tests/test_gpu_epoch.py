@@ -360,3 +360,55 @@ def test_a2c_learn_tiles_tiny_ragged_batches(obs_size, A, hidden, B):
     assert abs(v - e) <= 2e-6 * abs(e) + 2e-7, (k, v, e)
   got = ctl._flat.dense(grad=True).cpu()
   np.testing.assert_allclose(got.numpy(), exp_grad.numpy(), rtol=1e-4, atol=2e-5 * float(exp_grad.abs().max()))
+
+
+# ---------------------------------------------------------------- forward only through the tile pipeline (trl_ac_forward_tiles)
+FWD_CASES = [(8, 4, (256,), 5000), (17, 6, (256,), 70001), (12, 3, (128,), 63), (15, 2, (64, 48), 40000), (3, 4, (32, 32), 1),
+             (31, 5, (64,), 999), (24, 1, (256,), 33000)]
+
+
+@pytest.mark.parametrize('obs_size,A,hidden,B', FWD_CASES)
+def test_forward_tiles_matches_the_modules(obs_size, A, hidden, B):
+  """values = critic(obs), mean = actor(obs), log_probs = Normal(mean, exp(log_std)).log_prob(action)
+  (ppo_controller.py:32-51's forward passes) from the tile pipeline against the torch modules on the CPU."""
+  ctl = _make(obs_size, A, hidden, 2 * B + A)
+  assert ctl._tiles is not None
+  ref = copy.deepcopy(ctl.ac_net).cpu()
+  g = torch.Generator().manual_seed(B)
+  obs, act = torch.randn(B, obs_size, generator=g), torch.randn(B, A, generator=g)
+  with torch.no_grad():
+    ev, em = ref.critic(obs).view(-1), ref.actor(obs)
+    el = torch.distributions.Normal(em, ref.log_std.exp().expand_as(em)).log_prob(act)
+  v, m, l = ctl._tiles.forward_tiles(obs.to(DEV), act.to(DEV), want_mean=True)
+  torch.cuda.synchronize()
+  torch.testing.assert_close(v.cpu(), ev, rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(m.cpu(), em, rtol=1e-5, atol=2e-6)
+  torch.testing.assert_close(l.cpu(), el, rtol=2e-5, atol=2e-5)
+  v2 = ctl._tiles.forward_tiles(obs.to(DEV), critic_only=True)[0]
+  assert torch.equal(v2, v)                      # the critic alone: the same values
+
+
+@pytest.mark.parametrize('kind', ['ppo', 'a2c'])
+def test_compute_return_on_wide_nets_uses_the_tile_forward(kind):
+  """compute_return_batched for a 17-observation, 6-action net of the reference's default width: the forward passes
+  come from the tile pipeline and the results are the layer path's (fused=False) up to f32 summation order."""
+  from torchrl_amd.contrib.controllers import A2CController
+  T, N, obs_size, A = 40, 48, 17, 6
+  mk = (lambda fused: PPOController(obs_size, A, lmbda=0.95, device=DEV, fused=fused)) if kind == 'ppo' else \
+      (lambda fused: A2CController(obs_size, A, device=DEV, fused=fused))
+  torch.manual_seed(3)
+  a, b = mk(None), mk(False)
+  b.ac_net.load_state_dict(a.ac_net.state_dict())
+  assert a._fused is None and a._tiles is not None and b._tiles is None
+  g = torch.Generator(device=DEV).manual_seed(4)
+  obs = torch.randn(T, N, obs_size, device=DEV, generator=g)
+  reward = torch.randn(T, N, device=DEV, generator=g)
+  last_obs = torch.randn(N, obs_size, device=DEV, generator=g)
+  last_done = (torch.rand(N, device=DEV, generator=g) < 0.3).float()
+  if kind == 'ppo':
+    action = torch.randn(T, N, A, device=DEV, generator=g)
+    ra, rb = a.compute_return_batched(obs, action, reward, last_obs, last_done), b.compute_return_batched(obs, action, reward, last_obs, last_done)
+  else:
+    ra, rb = a.compute_return_batched(obs, reward, last_obs, last_done), b.compute_return_batched(obs, reward, last_obs, last_done)
+  for x, y in zip(ra, rb):
+    torch.testing.assert_close(x.reshape(-1), y.reshape(-1), rtol=2e-5, atol=2e-5)

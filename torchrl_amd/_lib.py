@@ -132,6 +132,7 @@ PROTOTYPES = {
                                       _f64, _f64, _vp, C.POINTER(AdamArgs), _i32, _vp, _vp]),
     'trl_a2c_learn_tiles': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _vp,
                                       C.POINTER(AdamArgs), _i32, _vp, _vp]),
+    'trl_ac_forward_tiles': (C.c_int, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     'trl_ddpg_learn_workspace_bytes': (_i64, [C.POINTER(MlpDesc), C.POINTER(MlpDesc), _i64]),
     'trl_offpolicy_set_chain': (None, [_i32]),
     'trl_ddpg_learn_fused': (C.c_int, [C.POINTER(MlpDesc)] * 4 + [_vp] * 5 + [_i64, _f64, _i32, _f64, _vp,

@@ -76,6 +76,10 @@ class A2CController(Controller):
       if self._fused is not None and self._fused.usable(flat_obs) and self._fused.usable(last_next_obs):
         values = self._fused.forward(flat_obs, want_mean=False)[0]      # forward-only kernel
         bootstrap = self._fused.forward(last_next_obs, want_mean=False)[0]
+      elif (self._tiles is not None and flat_obs.is_cuda and flat_obs.dtype == torch.float32
+            and flat_obs.shape[0] >= 32):
+        values = self._tiles.forward_tiles(flat_obs)[0]                 # the tile pipeline, forward only, critic alone
+        bootstrap = self._tiles.forward_tiles(last_next_obs)[0]
       else:
         values = self.ac_net.critic(flat_obs)
         bootstrap = self.ac_net.critic(last_next_obs).view(N)

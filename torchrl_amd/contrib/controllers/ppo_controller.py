@@ -110,6 +110,15 @@ class PPOController(Controller):
         returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
                              env_major_out=env_major_out)
         return returns, adv, log_probs.view(T, N, -1), values
+      if self._tiles_forward_ok(flat_obs):
+        # shapes outside the register-chained kernels: the tile pipeline, forward only (trl_ac_forward_tiles)
+        values, _, log_probs = self._tiles.forward_tiles(flat_obs, action.reshape(T * N, -1))
+        bootstrap = self._tiles.forward_tiles(last_next_obs, critic_only=True)[0]
+        bootstrap = torch.where(last_done.reshape(N) != 0, torch.zeros_like(bootstrap), bootstrap)
+        values = values.view(T, N)
+        returns, adv = F.gae(reward, values, bootstrap, self.gamma, self.lmbda, done=done, masked=masked,
+                             env_major_out=env_major_out)
+        return returns, adv, log_probs.view(T, N, -1), values
       values, mean, log_std = self.ac_net.heads(flat_obs)
       values = values.view(T, N)
       bootstrap = self.ac_net.critic(last_next_obs).view(N)
@@ -118,6 +127,10 @@ class PPOController(Controller):
                            env_major_out=env_major_out)
       log_probs = F.normal_log_prob(mean, log_std, action.reshape(T * N, -1)).view(T, N, -1)
     return returns, adv, log_probs, values
+
+  def _tiles_forward_ok(self, flat_obs):
+    return (self._tiles is not None and flat_obs.is_cuda and flat_obs.dtype == torch.float32
+            and flat_obs.shape[0] >= self.TILES_MIN_BATCH)
 
   def _compute_return_blocked(self, obs, action, reward, last_next_obs, last_done, done, masked, env_major_out):
     G, T, E = reward.shape
@@ -128,6 +141,9 @@ class PPOController(Controller):
       if self._fused is not None and self._fused.usable(flat_obs) and self._fused.usable(last_next_obs):
         values, _, log_probs = self._fused.forward(flat_obs, flat_act, want_mean=False)
         bootstrap, _, _ = self._fused.forward(last_next_obs, want_mean=False)
+      elif self._tiles_forward_ok(flat_obs):
+        values, _, log_probs = self._tiles.forward_tiles(flat_obs, flat_act)
+        bootstrap = self._tiles.forward_tiles(last_next_obs, critic_only=True)[0]
       else:
         values, mean, log_std = self.ac_net.heads(flat_obs)
         bootstrap = self.ac_net.critic(last_next_obs).view(N)

@@ -79,6 +79,10 @@ struct Args {
   // adv_out[row] = returns[row] - V(row) on their way, the actor's launch behind them reads it as `adv`
   int role_base;
   float *adv_out;
+  // forward only (trl_ac_forward_tiles): the tiles stop behind the loss phase, whose waves write the critic's value /
+  // the actor's mean and Normal log-prob of `action` instead; nothing else leaves the kernel
+  int fwd_only;
+  float *fwd_value, *fwd_mean, *fwd_logp;
 };
 
 // LDS map of one workgroup (offsets in floats).  Aliases: g2 (the [sample][feature] copy of layer 1's output gradient)
@@ -720,6 +724,11 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
           const float d = cur_act[0] - outa;
           const float sq = d * d;
           const float lp = ((-sq) / den - logsig) - LOG_SQRT_2PI;
+          if (TILES && P.fwd_only && ok) {
+            const int64_t at = (base + (int64_t)t * S + lane) * O + a;
+            if (P.fwd_mean) P.fwd_mean[at] = outa;
+            if (P.fwd_logp) P.fwd_logp[at] = lp;
+          }
           const float ratio = expf(lp - cur_old[0]);
           const float s1 = ratio * cur_adv;
           const float rc = fminf(fmaxf(ratio, P.lo), P.hi);
@@ -747,6 +756,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
         }
         if (role == 0) {      // critic: mse_loss(values, returns), weight alpha
           if (TILES && P.adv_out && ok) P.adv_out[base + (int64_t)t * S + lane] = cur_ret - out[0];
+          if (TILES && P.fwd_only && ok) P.fwd_value[base + (int64_t)t * S + lane] = out[0];
           const float dv = out[0] - cur_ret;
           const float g = ok ? P.alpha * ((2.0f * invB) * dv) : 0.f;
           a_crit += ok ? dv * dv : 0.f;
@@ -795,9 +805,10 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       }
       __syncthreads();
       STAMP(3);
+      const bool bwd = !(TILES && P.fwd_only);      // (forward only: the tile ends here)
       // ---- lane = feature: dwL[o][n] += sum_s gout[s][o] h[n][s];  g[n][s] = (sum_o gout[s][o] wL[o][n]) (h > 0), written
       // over h's image and (two hidden layers) as the [sample][feature] copy the next product sums over
-      if (gp_on) {
+      if (bwd && gp_on) {
         float wl_n[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) wl_n[o] = vpp[o * HL + gp_n];
@@ -842,7 +853,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       }
       __syncthreads();
       STAMP(4);
-      if (D3) {
+      if (D3 && bwd) {
         // ---- dW1[n][k] += sum_s g2[n][s] h1[k][s]
         if (T1 == 2 && own1[T1 - 1]) {
           mma2<LS, LS>(h2t + r1[0] * LS, h2t + r1[T1 - 1] * LS, h1t + c1[0] * LS, h1t + c1[T1 - 1] * LS, S, acc1[0], acc1[T1 - 1], i, q);
@@ -869,7 +880,8 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
       }
       STAMP(6);
       // ---- dW0'[n][j] += sum_s g1[n][s] x'[j][s]
-      if (WIDE) {      // a row tile's two column tiles share its operand
+      if (!bwd) {
+      } else if (WIDE) {      // a row tile's two column tiles share its operand
 #pragma unroll
         for (int u = 0; u < T1; ++u)
           if (own0[u]) {
@@ -895,6 +907,7 @@ __device__ __forceinline__ void epoch_body(const Args &P, float *lds) {
     }
     const int t = 0;      // (for the stamps below)
     (void)t;
+    if (TILES && P.fwd_only) return;
 
     // ---- the update.  Layer 0's gradient tile -> LDS (its state is spread one element per thread); partial sums of
     // the lane = feature pass; the loss values and the gradients that come out of them.  (Two hidden layers: the
@@ -1594,4 +1607,92 @@ extern "C" int trl_a2c_learn_tiles(const trl_mlp_desc *critic, const trl_mlp_des
                                    void *ws, void *stream) {
   return learn_tiles_impl("trl_a2c_learn_tiles", 1, critic, actor, nullptr, obs, action, returns, nullptr, adv, B, A, 0.0,
                           alpha, beta, losses_out, adam, update, ws, stream);
+}
+
+// ---- forward only through the tile pipeline: V(obs), the actor's mean and Normal(mean, exp(log_std)).log_prob(action)
+// (ppo_controller.py:32-51's forward passes; a2c_controller.py:30's values) for the shapes trl_ppo_forward_fused does not
+// take -- the tiles stop behind the loss phase, whose waves write the outputs.  actor == NULL: the critic alone.
+extern "C" int trl_ac_forward_tiles(const trl_mlp_desc *critic, const trl_mlp_desc *actor, const float *log_std,
+                                    const float *obs, const float *action, int64_t B, int32_t A, float *value_out,
+                                    float *mean_out, float *logp_out, void *stream) {
+  const char *fn = "trl_ac_forward_tiles";
+  TRL_REQUIRE(critic && obs && value_out, "%s: NULL argument", fn);
+  TRL_REQUIRE(!actor || (log_std && (mean_out || logp_out) && (!logp_out || action)),
+              "%s: the actor's pass needs log_std, an output and (for log-probs) the actions", fn);
+  TRL_REQUIRE(B >= 1 && B <= (1ll << 31) - 64, "%s: bad batch size", fn);
+  if (!actor) A = 1;
+  TRL_REQUIRE(A >= 1 && A <= MAXO_T, "%s: action size %d must be in [1, %d]", fn, A, MAXO_T);
+  const bool wide = A > MAXO || critic->dims[0] > KP - 1;
+  TRL_REQUIRE(!wide || (critic->depth == 2 && (!actor || actor->depth == 2)),
+              "%s: more than %d observations or %d actions need networks of ONE hidden layer", fn, KP - 1, MAXO);
+  const int kp = wide ? KPW : KP;
+  // the kernels address parameters as offsets into one buffer: the span of these networks' parameters
+  const trl_mlp_desc *nets[2] = {critic, actor};
+  const float *lo = nullptr, *hi = nullptr;
+  auto span = [&](const float *p, int64_t n) {
+    if (!lo || p < lo) lo = p;
+    if (!hi || p + n > hi) hi = p + n;
+  };
+  for (int r = 0; r < (actor ? 2 : 1); ++r) {
+    TRL_REQUIRE(nets[r]->depth == 2 || nets[r]->depth == 3, "%s: depth 2 or 3 (one or two hidden layers)", fn);
+    for (int l = 0; l < nets[r]->depth; ++l) {
+      TRL_REQUIRE(nets[r]->w[l] && nets[r]->b[l], "%s: a network has a NULL parameter", fn);
+      span(nets[r]->w[l], (int64_t)nets[r]->dims[l + 1] * nets[r]->dims[l]);
+      span(nets[r]->b[l], nets[r]->dims[l + 1]);
+    }
+  }
+  if (actor) span(log_std, A);
+  trl_adam_args flat = {};
+  flat.param = const_cast<float *>(lo);
+  flat.n = hi - lo;
+  Args P = {};
+  int rc;
+  if ((rc = fill_net(fn, "critic", critic, &flat, 1, P.net[0], kp))) return rc;
+  if (actor) {
+    if ((rc = fill_net(fn, "actor", actor, &flat, A, P.net[1], kp))) return rc;
+    TRL_REQUIRE(P.net[0].d0 == P.net[1].d0 && P.net[0].depth == P.net[1].depth,
+                "%s: critic and actor must have the same fan-in and depth", fn);
+    P.net[1].ls_off = log_std - lo;
+  } else {
+    P.net[1] = P.net[0];
+  }
+  int64_t lds_bytes = 0;
+  for (int r = 0; r < (actor ? 2 : 1); ++r) {
+    const int64_t b = (int64_t)make_lay(P.net[r], kp).total * 4;
+    lds_bytes = b > lds_bytes ? b : lds_bytes;
+  }
+  TRL_REQUIRE(lds_bytes <= MAX_LDS_BYTES, "%s: networks of this size need %lld B of LDS (limit %lld)", fn,
+              (long long)lds_bytes, (long long)MAX_LDS_BYTES);
+  const bool split = B >= 4 * MAX_SLABS * S;
+  int G;
+  slab_plan(B, &P.slab, &G, split || !actor ? 2 * MAX_SLABS : MAX_SLABS);
+  P.param = flat.param;
+  P.obs = obs;
+  // the loss inputs the forward does not use are read all the same: any readable column of the right length
+  P.action = action ? action : (logp_out ? logp_out : mean_out);
+  P.returns = value_out; P.adv = value_out; P.old_logp = logp_out ? logp_out : mean_out;
+  P.n_rows = B; P.n_epochs = 1; P.A = A;
+  P.lo = 0.f; P.hi = 2.f; P.clip = __builtin_inff();
+  P.lpart = value_out;      // (never written: the kernel returns ahead of its sums)
+  P.fwd_only = 1; P.fwd_value = value_out; P.fwd_mean = mean_out; P.fwd_logp = logp_out;
+  hipStream_t st = (hipStream_t)stream;
+  EpochKernel kern = wide ? pick_tiles_kernel_wide(0, A) : pick_tiles_kernel(P.net[0].depth == 3, A);
+  if (lds_bytes > 48 * 1024 &&
+      hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess) {
+    (void)hipGetLastError();
+    trl_set_error("%s: could not raise the kernel's LDS limit", fn);
+    return TRL_EHIP;
+  }
+  if (!actor) {
+    hipLaunchKernelGGL(kern, dim3(1, G), dim3(NT), (size_t)lds_bytes, st, P);
+  } else if (split) {
+    hipLaunchKernelGGL(kern, dim3(1, G), dim3(NT), (size_t)lds_bytes, st, P);
+    TRL_CHECK_LAUNCH(fn);
+    P.role_base = 1;
+    hipLaunchKernelGGL(kern, dim3(1, G), dim3(NT), (size_t)lds_bytes, st, P);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(2, G), dim3(NT), (size_t)lds_bytes, st, P);
+  }
+  TRL_CHECK_LAUNCH(fn);
+  return TRL_OK;
 }

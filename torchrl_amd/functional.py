@@ -961,6 +961,36 @@ class FusedPpoLearn:
         return False
     return True
 
+  def forward_tiles(self, obs, action=None, want_mean=False, critic_only=False):
+    """No-grad forward through the tile pipeline (trl_ac_forward_tiles) for the shapes tiles_supports() takes:
+    (value [B], mean [B, A] | None, logp [B, A] | None); logp = Normal(mean, exp(log_std)).log_prob(action) per
+    dimension when `action` is given (PPO).  critic_only (or an A2C object: no log_std): the values alone."""
+    C = self._C
+    obs = _f32c(obs, 'obs')
+    B, dev = obs.shape[0], obs.device
+    if obs.dim() != 2 or obs.shape[1] != self.K0:
+      raise ValueError('ac_forward_tiles: obs must be [B, %d]' % self.K0)
+    if self._ptr_key() != self._key:
+      self._bind()
+    critic_only = critic_only or self.log_std is None or (action is None and not want_mean)
+    value = torch.empty(B, dtype=torch.float32, device=dev)
+    mean = logp = None
+    if not critic_only:
+      if action is not None:
+        action = _f32c(action, 'action')
+        if action.numel() != B * self.A:
+          raise ValueError('ac_forward_tiles: action must be [B, %d]' % self.A)
+        logp = torch.empty((B, self.A), dtype=torch.float32, device=dev)
+      if want_mean or logp is None:
+        mean = torch.empty((B, self.A), dtype=torch.float32, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    with torch.cuda.device(dev):
+      _lib.check(_lib.lib().trl_ac_forward_tiles(
+          C.byref(self.descs[0]), None if critic_only else C.byref(self.descs[1]),
+          None if critic_only else self.log_std.data_ptr(), obs.data_ptr(), ptr(action) if not critic_only else None, B,
+          self.A, value.data_ptr(), ptr(mean), ptr(logp), _lib.stream_ptr(dev)))
+    return value, mean, logp
+
   def a2c_tiles(self, obs, action, returns, alpha, beta, adam, update=True):
     """A2CController.learn's device work through the tile pipeline (trl_a2c_learn_tiles) for the A2CNet shapes the
     register-chained kernels do not take (three to six actions, a wide layer over 10 - 31 observations): the detached
