@@ -702,7 +702,8 @@ def bench_a2c(args, rank, world, dev):
 def wide_nets(dev, B=1 << 20):
   """One learn() over a 1 M-row batch on the reference's default width (256) with more observations / actions than the
   whole-step kernels of csrc/trl_learn.hip take: the tile pipeline spread over the chip (csrc/trl_epoch.hip:
-  trl_ppo_learn_tiles / trl_a2c_learn_tiles) against the layer-by-layer path (fused=False) of the same controller."""
+  trl_ppo_learn_tiles / trl_a2c_learn_tiles) against the layer-by-layer path (fused=False) of the same controller;
+  and compute_return_batched over the same rows (trl_ac_forward_tiles against the module path)."""
   rows = []
   for kind, obs_size, A in (('ppo', 8, 4), ('ppo', 17, 6), ('a2c', 8, 4), ('a2c', 17, 6)):
     g = torch.Generator(device=dev).manual_seed(obs_size + A)
@@ -726,9 +727,27 @@ def wide_nets(dev, B=1 << 20):
       for _ in range(5):
         fn()
       torch.cuda.synchronize()
-      key = 'ms_learn_tiles' if fused and getattr(c, '_tiles', None) is not None and c._fused is None else \
-          ('ms_learn' if fused else 'ms_learn_layer_path')
+      tiles = fused and getattr(c, '_tiles', None) is not None and c._fused is None
+      key = 'ms_learn_tiles' if tiles else ('ms_learn' if fused else 'ms_learn_layer_path')
       row[key] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+      # compute_return over the same rows as a [T, N] rollout: the forward passes through trl_ac_forward_tiles / the modules
+      T, N = 2048, B // 2048
+      ob3, rew = o.view(T, N, obs_size), r.view(T, N)
+      last_obs, last_done = o[:N], torch.zeros(N, device=dev)
+      if kind == 'ppo':
+        act3 = a.view(T, N, A)
+        fr = lambda: c.compute_return_batched(ob3, act3, rew, last_obs, last_done)  # noqa: E731
+      else:
+        fr = lambda: c.compute_return_batched(ob3, rew, last_obs, last_done)  # noqa: E731
+      for _ in range(2):
+        fr()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(5):
+        fr()
+      torch.cuda.synchronize()
+      row['ms_compute_return_tiles' if tiles else ('ms_compute_return' if fused else 'ms_compute_return_module_path')] = \
+          round((time.perf_counter() - t0) / 5 * 1e3, 3)
       del c
     rows.append(row)
   return rows
